@@ -1,0 +1,449 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); the GPU box never
+sees the reference, only the ``.npz`` files this script writes.  Fixtures are
+data only: inputs and the reference's outputs on them.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [names...]
+
+Fixture list follows SURVEY.md section 8c (F1..F8).
+"""
+import os
+import sys
+import time
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = "/root/reference/knode_cosserat"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import cosserat_ode as ref_ode  # noqa: E402  (reference)
+import cosserat_ode_torch as ref_torch  # noqa: E402
+import knode as ref_knode  # noqa: E402
+import physics_controls as ref_ctl  # noqa: E402
+from Utils.transformations import quaternion_to_euler as ref_q2e  # noqa: E402
+
+import cosserat_oracle as orc  # only for make_mlp / batch_sine_controls (input generators)
+
+torch.set_num_threads(1)
+MODS = [None, "noair", "nsw", "short", "damping", "dampstiff", "lengthstiff", "youngs"]
+ACT_MODULE = {"tanh": nn.Tanh, "softplus": nn.Softplus, "relu": nn.ReLU, "elu": nn.ELU}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def np_robot(mod="default", N=10, use_fsolve=True):
+    r = ref_ode.CosseratRod(use_fsolve=use_fsolve)
+    if mod != "default":
+        ref_knode.setup_robot(r, mod)
+    r.N = N
+    r.compute_intermediate_terms()
+    return r
+
+
+def torch_module_list(mlp):
+    """nn.ModuleList with the layer order the reference walks by str()."""
+    mods = []
+    names = {v: k for k, v in orc._ACT_BY_NAME.items() if k != "identity"}
+    for W, b, act in zip(mlp.weights, mlp.biases, mlp.acts):
+        lin = nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            lin.weight.copy_(torch.tensor(W))
+            lin.bias.copy_(torch.tensor(b))
+        mods.append(lin)
+        if act != orc.ACT_NONE:
+            mods.append(ACT_MODULE[names[act]]())
+    return nn.ModuleList(mods)
+
+
+def inject_nn(robot, mlp):
+    """What physics_train.py:104-110 does to switch the NumPy rod to NN mode."""
+    ml = torch_module_list(mlp)
+    robot.nn_model = ml
+    robot.param_ls = [t.detach().cpu().numpy() for _, t in ml.state_dict().items()]
+    robot.nn_path = "whatever"
+    robot.nn_input_history = mlp.history
+
+
+def mlp_arrays(prefix, mlp):
+    d = {}
+    for k, (W, b) in enumerate(zip(mlp.weights, mlp.biases)):
+        d[f"{prefix}_W{k}"] = W
+        d[f"{prefix}_b{k}"] = b
+    d[f"{prefix}_acts"] = np.array(mlp.acts, dtype=np.int32)
+    d[f"{prefix}_history"] = np.array(int(mlp.history))
+    return d
+
+
+def sample_rows(Q, seed):
+    """Rows with the scale of a real trajectory: states of a short reference
+    run (N=10, sine) jittered; quaternion deliberately not normalised."""
+    rng = np.random.default_rng(seed)
+    r = np_robot(None, 10)
+    ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, 24)
+    traj = ref_knode.simulate(r, ctl)
+    ys, yhs, zhs = [], [], []
+    for _ in range(Q):
+        t = rng.integers(2, traj.shape[0])
+        j = rng.integers(0, 10)
+        y = traj[t, :19, j].copy()
+        y *= 1 + 0.2 * rng.standard_normal(19)
+        y += 1e-3 * rng.standard_normal(19)
+        y[3:7] *= rng.uniform(0.7, 1.4)
+        ys.append(y)
+        yhs.append(traj[t, 25:44, j] * (1 + 0.1 * rng.standard_normal(19)))
+        zhs.append(traj[t, 44:50, j] * (1 + 0.1 * rng.standard_normal(6)))
+    tens = 5 + 2 * rng.random((Q, 4))
+    return np.array(ys), np.array(yhs), np.array(zhs), tens
+
+
+NN_VARIANTS = [
+    ("elu64", [28, 64, 25], "elu", False),
+    ("hist64", [53, 64, 25], "elu", True),
+    ("tanh6464", [28, 64, 64, 25], "tanh", False),
+    ("softplus6464", [28, 64, 64, 25], "softplus", False),
+    ("relu6464", [28, 64, 64, 25], "relu", False),
+    ("elu6464", [28, 64, 64, 25], "elu", False),
+]
+
+
+def gen_ode_kat():
+    """F1: CosseratRod.ODE on random rows x presets x NN variants."""
+    Q = 48
+    y, yh, zh, tens = sample_rows(Q, 0)
+    out = {"y": y, "yh": yh, "zh": zh, "tensions": tens}
+    for mod in ["default"] + MODS:
+        r = np_robot(mod, 10)
+        res = np.zeros((Q, 25))
+        for i in range(Q):
+            tf = tens[i] @ r.tendon_dirs
+            ys, z = r.ODE(y[i].copy(), yh[i], zh[i], tf)
+            res[i] = np.concatenate([ys, z])
+        out[f"phys_{mod}"] = res
+    for k, (name, sizes, act, hist) in enumerate(NN_VARIANTS):
+        mlp = orc.make_mlp(sizes, act, seed=100 + k, history=hist)
+        # scale the weights up so the correction is not negligible next to the physics
+        mlp.weights = [w * 3 for w in mlp.weights]
+        r = np_robot(None, 10)
+        inject_nn(r, mlp)
+        res = np.zeros((Q, 25))
+        for i in range(Q):
+            tf = tens[i] @ r.tendon_dirs
+            ys, z = r.ODE(y[i].copy(), yh[i], zh[i], tf)
+            res[i] = np.concatenate([ys, z])
+        out[f"nn_{name}"] = res
+        out.update(mlp_arrays(f"mlp_{name}", mlp))
+    save("ode_kat", **out)
+
+
+def gen_ode_torch_kat():
+    """F2: the torch twin, serial ODE and ODE_parallel, fp32."""
+    Q = 48
+    y, yh, zh, tens = sample_rows(Q, 0)
+    out = {}
+    for name, sizes, act, hist in [NN_VARIANTS[0], NN_VARIANTS[1], NN_VARIANTS[5]]:
+        k = [v[0] for v in NN_VARIANTS].index(name)
+        mlp = orc.make_mlp(sizes, act, seed=100 + k, history=hist)
+        mlp.weights = [w * 3 for w in mlp.weights]
+        rob = ref_torch.CosseratRodTorch("cpu", 64, nn_input_history=hist)
+        ref_knode.setup_robot(rob, None)
+        rob.nn_models = torch_module_list(mlp)
+        ty, tyh, tzh = (torch.tensor(a).float() for a in (y, yh, zh))
+        tf = torch.tensor(tens).float() @ rob.tendon_dirs
+        for use_nn in (False, True):
+            rob.use_nn = use_nn
+            with torch.no_grad():
+                dys, z = rob.ODE_parallel(ty, tyh, tzh, tf)
+                par = torch.cat([dys, z], 1).numpy()
+                ser = np.zeros((Q, 25), np.float32)
+                for i in range(Q):
+                    a, b = rob.ODE(ty[i].clone(), tyh[i], tzh[i], tf[i])
+                    ser[i] = torch.cat([a, b]).numpy()
+            out[f"par_{name}_{int(use_nn)}"] = par
+            out[f"ser_{name}_{int(use_nn)}"] = ser
+    save("ode_torch_kat", **out)
+
+
+def converged_state(r, T, ctl_fn):
+    """Run the reference T steps and return (y, z, y_prev, z_prev, G, tensions)
+    from which one more residual can be evaluated."""
+    ctl = ctl_fn(T + 1)
+    traj = ref_knode.simulate(r, ctl)
+    y, z = traj[T - 1, :19].copy(), traj[T - 1, 19:25].copy()
+    yp, zp = traj[T - 2, :19].copy(), traj[T - 2, 19:25].copy()
+    return y, z, yp, zp, traj[T - 1, 7:13, 0].copy(), np.array(ctl[T - 1], float)
+
+
+def gen_residual_kat():
+    """F3: getResidualEuler / getResidualRK4 6-vectors and the mutated y, z."""
+    rng = np.random.default_rng(1)
+    out = {}
+    for N, mod in [(10, None), (20, None), (100, None), (10, "default"), (40, "default")]:
+        r = np_robot(mod, N)
+        y, z, yp, zp, G0, tens = converged_state(
+            r, 6, lambda T: ref_ctl.calc_controls("sine", 1.0, r.del_t, T))
+        yh = r.c1 * y + r.c2 * yp
+        zh = r.c1 * z + r.c2 * zp
+        yh_int = 0.5 * (yh[:, :-1] + yh[:, 1:])
+        zh_int = 0.5 * (zh[:, :-1] + zh[:, 1:])
+        r.tendon_tensions = tens
+        tag = f"N{N}_{mod}"
+        out[f"{tag}_y"], out[f"{tag}_z"], out[f"{tag}_yp"], out[f"{tag}_zp"] = y, z, yp, zp
+        out[f"{tag}_tens"] = tens
+        Gs = G0[None, :] * (1 + 0.05 * rng.standard_normal((3, 6))) + 1e-3 * rng.standard_normal((3, 6))
+        out[f"{tag}_G"] = Gs
+        for scheme, fn in (("euler", r.getResidualEuler), ("rk4", r.getResidualRK4)):
+            rs, ys, zs = [], [], []
+            for G in Gs:
+                yy, zz = y.copy(), z.copy()
+                with np.errstate(all="ignore"):
+                    rs.append(fn(G, yy, zz, yh, yh_int, zh, zh_int))
+                ys.append(yy)
+                zs.append(zz)
+            out[f"{tag}_{scheme}_r"] = np.array(rs)
+            out[f"{tag}_{scheme}_y"] = np.array(ys)
+            out[f"{tag}_{scheme}_z"] = np.array(zs)
+    save("residual_kat", **out)
+
+
+class FsolveSpy:
+    """Wraps scipy's fsolve so that ier / nfev of every step are recorded;
+    the reference discards them (knode.py:89)."""
+
+    def __init__(self):
+        from scipy.optimize import fsolve
+        self._f = fsolve
+        self.ier, self.nfev = [], []
+
+    def __call__(self, fun, x0, args=()):
+        x, info, ier, _ = self._f(fun, x0, args=args, full_output=True)
+        self.ier.append(ier)
+        self.nfev.append(info["nfev"])
+        return x
+
+
+def run_sim(r, ctl, scheme="euler"):
+    spy = FsolveSpy()
+    old = ref_knode.fsolve
+    ref_knode.fsolve = spy
+    if scheme == "rk4":
+        r_euler = r.getResidualEuler
+        r.getResidualEuler = r.getResidualRK4  # knode.simulate hard-codes the Euler residual (knode.py:89)
+    try:
+        with np.errstate(all="ignore"):
+            traj = ref_knode.simulate(r, ctl)
+    finally:
+        ref_knode.fsolve = old
+        if scheme == "rk4":
+            r.getResidualEuler = r_euler
+    return traj, np.array(spy.ier), np.array(spy.nfev)
+
+
+def gen_sim_cfg1():
+    """F4: BASELINE config 1 - single rod, N=20, 200 steps, tensions [6,5,5,6]."""
+    r = np_robot(None, 20)
+    ctl = [[6.0, 5.0, 5.0, 6.0]] * 200
+    t0 = time.time()
+    traj, ier, nfev = run_sim(r, ctl)
+    print(f"  cfg1: {200/(time.time()-t0):.1f} rod-steps/s, mean nfev {nfev.mean():.1f}")
+    save("sim_cfg1", ctl=np.array(ctl), tip=traj[:, :3, -1], every10=traj[::10, :25], last=traj[-1],
+         ier=ier, nfev=nfev)
+
+
+def gen_sim_n100():
+    """F5a: N=100, T=50, sine(1.0); plus a small cfg2-style random-phase batch."""
+    r = np_robot(None, 100)
+    ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, 50)
+    traj, ier, nfev = run_sim(r, ctl)
+    out = dict(ctl=np.array(ctl), tip=traj[:, :3, -1], every10=traj[::10, :25], last=traj[-1], ier=ier, nfev=nfev)
+    B, T = 6, 24
+    ctl_b = orc.batch_sine_controls(B, T, r.del_t, 1234)
+    tips, iers = [], []
+    for b in range(B):
+        tr, ie, _ = run_sim(r, ctl_b[b])
+        tips.append(tr[:, :3, -1])
+        iers.append(ie)
+    out.update(batch_ctl=ctl_b, batch_tip=np.array(tips), batch_ier=np.array(iers))
+    save("sim_n100", **out)
+
+
+def gen_sim_n400():
+    """F5b: N=400, T=12, sine(1.0)."""
+    r = np_robot(None, 400)
+    ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, 12)
+    traj, ier, nfev = run_sim(r, ctl)
+    save("sim_n400", ctl=np.array(ctl), tip=traj[:, :3, -1], last=traj[-1, :25], ier=ier, nfev=nfev)
+
+
+def gen_sim_misc():
+    """Presets, default parameters, step / random inputs, RK4 - short runs at small N."""
+    out = {}
+    for mod in MODS[1:] + ["default"]:
+        r = np_robot(mod, 10)
+        ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, 16)
+        traj, ier, _ = run_sim(r, ctl)
+        out[f"mod_{mod}_ctl"] = np.array(ctl)
+        out[f"mod_{mod}_traj"] = traj[:, :25]
+        out[f"mod_{mod}_ier"] = ier
+    r = np_robot(None, 10)
+    for kind, arg, T in (("step", 1.0, 40), ("random", 3.0, 20)):
+        ctl = ref_ctl.calc_controls(kind, arg, r.del_t, T)
+        traj, ier, _ = run_sim(r, ctl)
+        out[f"{kind}_ctl"] = np.array(ctl)
+        out[f"{kind}_traj"] = traj[:, :25]
+        out[f"{kind}_ier"] = ier
+    # full 50-row output once, to pin the [y; z; yh; zh] stacking and the [:-1] drop
+    ctl = ref_ctl.calc_controls("sine", 2.0, r.del_t, 8)
+    traj, ier, _ = run_sim(r, ctl)
+    out["full50_ctl"], out["full50_traj"], out["full50_ier"] = np.array(ctl), traj, ier
+    # RK4 (stable only for fine grids with the experimental preset)
+    r = np_robot(None, 40)
+    ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, 10)
+    traj, ier, _ = run_sim(r, ctl, scheme="rk4")
+    out["rk4_ctl"], out["rk4_traj"], out["rk4_ier"] = np.array(ctl), traj[:, :25], ier
+    save("sim_misc", **out)
+
+
+def gen_sim_nn():
+    """F6: forward simulation with the residual MLP switched on."""
+    out = {}
+    for name, sizes, act, hist, N, T in (("elu64", [28, 64, 25], "elu", False, 10, 30),
+                                         ("elu6464", [28, 64, 64, 25], "elu", False, 20, 20),
+                                         ("hist64", [53, 64, 25], "elu", True, 10, 20)):
+        mlp = orc.make_mlp(sizes, act, seed=0, history=hist)
+        if hist:
+            # history inputs are ~c1 * state, 40x larger: keep the correction small enough that the
+            # reference's own solve stays convergent
+            mlp.weights[0] = (mlp.weights[0] * 0.02).astype(np.float32)
+        r = np_robot(None, N)
+        inject_nn(r, mlp)
+        ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, T)
+        traj, ier, nfev = run_sim(r, ctl)
+        out[f"{name}_ctl"], out[f"{name}_traj"], out[f"{name}_ier"] = np.array(ctl), traj[:, :25], ier
+        out[f"{name}_N"] = np.array(N)
+        out.update(mlp_arrays(f"mlp_{name}", mlp))
+    save("sim_nn", **out)
+
+
+def four_term_loss(pred, target, kp_pred, kp_tgt):
+    """The loss of physics_train.py:252-259 / :345-352 built from the
+    reference's own pieces (nn.MSELoss + Utils.transformations)."""
+    mse = nn.MSELoss()
+    return (mse(pred[:3][:, kp_pred], target[:3, kp_tgt])
+            + mse(pred[7:19][:, kp_pred], target[7:19, kp_tgt])
+            + mse(ref_q2e(pred[3:7][:, kp_pred]), ref_q2e(target[3:7, kp_tgt]))
+            + mse(pred[19:][:, kp_pred], target[19:, kp_tgt - 1]))
+
+
+def gen_train_step():
+    """F7: one slow-path epoch and one --fast epoch of physics_train.py on a
+    fixed trajectory and fixed weights: predictions, loss, gradients and the
+    weights after Adam(lr=1e-2) + clamp(min=0)."""
+    out = {}
+    r = np_robot(None, 10)
+    ctl = np.array(ref_ctl.calc_controls("sine", 2.0, r.del_t, 30))
+    traj_np = ref_knode.simulate(r, ctl)[:, :25]
+    traj = torch.tensor(traj_np).float()
+    controls = torch.tensor(ctl).float()
+    out["traj"], out["controls"] = traj.numpy(), controls.numpy()
+    for H in (64,):
+        mlp = orc.make_mlp([28, H, 25], "elu", seed=7)
+        out.update(mlp_arrays("mlp", mlp))
+        for path in ("slow", "fast"):
+            rob = ref_torch.CosseratRodTorch("cpu", H)
+            ref_knode.setup_robot(rob, "damping")  # a preset that differs from the data generator, as in training
+            rob.nn_models = torch_module_list(mlp)
+            rob.use_nn = True
+            opt = torch.optim.Adam(rob.nn_models.parameters(), lr=1e-2, weight_decay=0)
+            loss = 0
+            preds = []
+            if path == "slow":
+                kp = torch.tensor([2, 6, 9])
+                for t in range(29):
+                    y, z = traj[t, :19], traj[t, 19:]
+                    yp, zp = (y, z) if t == 0 else (traj[t - 1, :19], traj[t - 1, 19:])
+                    rob.y, rob.z = y, z
+                    rob.tendon_tensions = controls[t]
+                    rob.residualArgs["yh"] = rob.c1 * y + rob.c2 * yp
+                    rob.residualArgs["zh"] = rob.c1 * z + rob.c2 * zp
+                    grow = rob.getNextSegmentEuler(traj[t + 1].clone())
+                    preds.append(grow.detach().numpy())
+                    loss = loss + four_term_loss(grow, traj[t + 1], kp, kp)
+            else:
+                kp = np.array([3, 5, 7, 9])
+                ys, zs = traj[:29, :19], traj[:29, 19:]
+                yps, zps = torch.cat((ys[:1], ys[:-1])), torch.cat((zs[:1], zs[:-1]))
+                grows = rob.parallelGetNextSegmentEuler(traj[1:30], kp, {
+                    "yh": rob.c1 * ys + rob.c2 * yps, "zh": rob.c1 * zs + rob.c2 * zps,
+                    "tendon_tensions": controls[:29]})
+                for t in range(29):
+                    preds.append(grows[t].detach().numpy())
+                    loss = loss + four_term_loss(grows[t], traj[t + 1], torch.arange(4), torch.tensor(kp))
+            loss = loss / 29
+            opt.zero_grad()
+            loss.backward()
+            grads = [p.grad.detach().numpy().copy() for p in rob.nn_models.parameters()]
+            opt.step()
+            with torch.no_grad():
+                for nm, p in rob.nn_models.named_parameters():
+                    if "weight" in nm and "layer1" not in nm:
+                        p.clamp_(min=0)
+            post = [p.detach().numpy().copy() for p in rob.nn_models.parameters()]
+            out[f"{path}_pred"] = np.array(preds)
+            out[f"{path}_loss"] = np.array(loss.item())
+            out[f"{path}_kp"] = np.asarray(kp)
+            for i, (gk, pk) in enumerate(zip(grads, post)):
+                out[f"{path}_grad{i}"] = gk
+                out[f"{path}_post{i}"] = pk
+        # no-NN self-consistency: the predictor reproduces the next state
+        rob.use_nn = False
+        with torch.no_grad():
+            t = 11
+            rob.tendon_tensions = controls[t]
+            rob.residualArgs["yh"] = rob.c1 * traj[t, :19] + rob.c2 * traj[t - 1, :19]
+            rob.residualArgs["zh"] = rob.c1 * traj[t, 19:] + rob.c2 * traj[t - 1, 19:]
+            out["nonn_pred_t11"] = rob.getNextSegmentEuler(traj[t + 1].clone()).numpy()
+    save("train_step", **out)
+
+
+def gen_small():
+    """F8: calc_controls and quaternion_to_euler."""
+    out = {}
+    for kind, arg, dt, T in (("sine", 1.0, 0.05, 40), ("sine", 2.5, 0.005, 25), ("step", 1.0, 0.05, 50),
+                             ("random", 3.0, 0.05, 30), ("random", 7.9, 0.05, 10)):
+        out[f"ctl_{kind}_{arg}_{dt}_{T}"] = np.array(ref_ctl.calc_controls(kind, arg, dt, T))
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((4, 400))
+    q[:, :40] = np.array([[1.0], [0.0], [0.0], [0.0]]) + 1e-3 * rng.standard_normal((4, 40))
+    # near the asin clamp: w*z - x*y ~ +-0.5
+    q[:, 40:60] = np.array([[1.0], [0.0], [0.0], [1.0]]) + 1e-4 * rng.standard_normal((4, 20))
+    q[:, 60:80] = np.array([[1.0], [0.0], [0.0], [-1.0]]) + 1e-4 * rng.standard_normal((4, 20))
+    out["quat"] = q
+    out["euler"] = ref_q2e(torch.tensor(q)).numpy()  # reference casts to float32 internally
+    save("small", **out)
+
+
+ALL = {
+    "ode_kat": gen_ode_kat, "ode_torch_kat": gen_ode_torch_kat, "residual_kat": gen_residual_kat,
+    "sim_cfg1": gen_sim_cfg1, "sim_n100": gen_sim_n100, "sim_n400": gen_sim_n400, "sim_misc": gen_sim_misc,
+    "sim_nn": gen_sim_nn, "train_step": gen_train_step, "small": gen_small,
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(ALL)
+    for n in names:
+        t0 = time.time()
+        print(f"[{n}]")
+        ALL[n]()
+        print(f"  {time.time()-t0:.1f} s")
