@@ -1,0 +1,227 @@
+/*
+ * knode_rod.h - C ABI of libknode_rod.so, the MI355X (gfx950) backend for the
+ * KNODE-Cosserat rod hot path.
+ *
+ * The reference (hsiehScalAR/KNODE-Cosserat) is pure Python and defines no FFI;
+ * its "interface" for this path is the duck-typed surface of
+ *   knode_cosserat/cosserat_ode.py        (class CosseratRod)
+ *   knode_cosserat/cosserat_ode_torch.py  (class CosseratRodTorch)
+ *   knode_cosserat/knode.py               (setup_robot, simulate)
+ * Every entry point below names the reference function (file:line) it
+ * replaces.  The Python shims in knode-cosserat_amd/ bind these symbols with
+ * ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - every function returns 0 on success, <0 on error (KR_E_*);
+ *    kr_last_error() gives the message of the calling thread's last error.
+ *  - all array arguments are DEVICE pointers owned by the caller unless the
+ *    name ends in _host; `stream` is a hipStream_t passed as void* (NULL = the
+ *    null stream).  Calls are asynchronous on that stream.
+ *  - one handle per (device, parameter set); a handle is not thread-safe,
+ *    distinct handles are.
+ *  - dtype selects the arithmetic type of the call: KR_F32 or KR_F64.  All
+ *    floating-point array arguments of a call have that element type.
+ *
+ * Rod state in HBM ("packed state", one record per grid point):
+ *    state[b][j][KR_SLOTS]     b < B rods, j < N grid points
+ *    slot  0.. 2  q   (y rows 13..15)     slot 12..14  p (y rows 0..2)
+ *    slot  3.. 5  w   (y rows 16..18)     slot 15..18  h (y rows 3..6)
+ *    slot  6.. 8  v   (z rows 0..2)       slot 19..21  n (y rows 7..9)
+ *    slot  9..11  u   (z rows 3..5)       slot 22..24  m (y rows 10..12)
+ *    slot 25..27  padding (kept zero)
+ * The twelve leading slots are exactly what the BDF2 history terms of the next
+ * step need (cosserat_ode.py:146-148 uses only q_t, w_t, v_t, u_t), so the
+ * solver reads 96 contiguous bytes (fp64) per grid point and writes one
+ * 16-byte-aligned record.  kr_state_pack / kr_state_unpack convert from/to
+ * the reference's feature-major arrays y[19][N], z[6][N].
+ */
+#ifndef KNODE_ROD_H
+#define KNODE_ROD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KR_SLOTS 28
+#define KR_NY 19
+#define KR_NZ 6
+#define KR_MAX_LAYERS 8
+
+enum { KR_F32 = 0, KR_F64 = 1 };
+enum { KR_EULER = 0, KR_RK4 = 1 };
+/* activation codes, cosserat_ode.py:99-108 */
+enum { KR_ACT_NONE = 0, KR_ACT_TANH = 1, KR_ACT_SOFTPLUS = 2, KR_ACT_RELU = 3, KR_ACT_ELU = 4 };
+/* per-rod solver status written by kr_step_batch */
+enum { KR_ST_CONVERGED = 0, KR_ST_MAXIT = 1, KR_ST_NONFINITE = 2 };
+
+enum {
+  KR_OK = 0,
+  KR_E_ARG = -1,     /* bad argument (null pointer, size, enum) */
+  KR_E_HIP = -2,     /* HIP runtime error */
+  KR_E_STATE = -3,   /* call order (e.g. NN requested but kr_set_mlp never called) */
+  KR_E_UNSUPPORTED = -4
+};
+
+/* Independent rod parameters, cosserat_ode.py:15-47 (NumPy class) /
+ * cosserat_ode_torch.py:14-45 (torch twin).  Matrices are row-major 3x3. */
+typedef struct kr_params {
+  double L;              /* rod length */
+  int32_t N;             /* grid points; segments = N-1; ds = L/(N-1) */
+  int32_t nn_input_history; /* 0: MLP input [y,z,tf] (28); 1: [y,yh,z,zh,tf] (53) */
+  double E, r, rho;      /* Young's modulus, radius, density */
+  double vstar[3];
+  double g[3];
+  double Bse[9];
+  double Bbt[9];
+  double C[3];
+  double del_t;
+  double F_tip[3];
+  double M_tip[3];
+  double tendon_dirs[12]; /* 4 x 3 */
+  double p0[3];
+  double h0[4];
+  double q0[3];
+  double w0[3];
+} kr_params;
+
+/* Dependent terms, cosserat_ode.py:58-78; returned so that the Python shim can
+ * expose the attributes estimate_state.py and the drivers read. */
+typedef struct kr_derived {
+  double A, G, ds, c0, c1, c2, rhoA;
+  double J[9], Kse[9], Kbt[9];
+  double Kse_plus_c0_Bse_inv[9];
+  double Kbt_plus_c0_Bbt_inv[9];
+  double Kse_vstar[3];
+  double rhoAg[3];
+  double rhoJ[9];
+} kr_derived;
+
+typedef struct kr_handle kr_handle;
+
+/* ---- library / handle ------------------------------------------------- */
+const char* kr_last_error(void);
+int kr_version(void);
+/* fills the struct with the reference's class defaults (cosserat_ode.py:15-47) */
+int kr_default_params(kr_params* out);
+/* applies knode.setup_robot (knode.py:6-53); mod NULL or "" = no modifier.
+ * Unknown mod -> KR_E_ARG, like the reference's exception. */
+int kr_apply_preset(kr_params* inout, const char* mod);
+
+int kr_create(const kr_params* p, int device, kr_handle** out);
+int kr_destroy(kr_handle* h);
+/* CosseratRod.compute_intermediate_terms, cosserat_ode.py:58-78 */
+int kr_set_params(kr_handle* h, const kr_params* p);
+int kr_get_derived(const kr_handle* h, kr_derived* out);
+/* same derivation without a handle or a GPU (host arithmetic only) */
+int kr_derive(const kr_params* p, kr_derived* out);
+
+/* Residual MLP, cosserat_ode.py:90-112 / cosserat_ode_torch.py:60-62,131-134.
+ * dims[n_layers+1]; W[k] is row-major [dims[k+1]][dims[k]] float32 (the dtype
+ * the reference trains and stores), b[k] is [dims[k+1]]; acts[k] is applied
+ * after layer k.  src_on_device: 0 = host pointers, 1 = device pointers.
+ * The library keeps its own packed copies.  n_layers = 0 switches the MLP off. */
+int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* acts,
+               const float* const* W, const float* const* b, int src_on_device, void* stream);
+
+/* CosseratRod.get_nn_output (cosserat_ode.py:90-112) on Q rows:
+ * x[Q][dims[0]] -> out[Q][25], row-major, f32 or f64 arithmetic. */
+int kr_mlp_eval_batch(kr_handle* h, int64_t Q, const void* x, void* out, int dtype, void* stream);
+
+/* ---- batched per-segment derivative ----------------------------------- */
+/* CosseratRodTorch.ODE_parallel (cosserat_ode_torch.py:217-322) and, row by
+ * row, CosseratRod.ODE (cosserat_ode.py:114-186).
+ * y[Q][19], yh[Q][19], zh[Q][6], tf[Q][3] -> dys[Q][19], z[Q][6], row-major.
+ * use_nn != 0 adds the MLP correction (needs kr_set_mlp). */
+int kr_ode_batch(kr_handle* h, int64_t Q, const void* y, const void* yh, const void* zh, const void* tf,
+                 void* dys, void* z, int use_nn, int dtype, void* stream);
+
+/* ---- packed state helpers --------------------------------------------- */
+/* knode.py:58-66: straight rod along +z, unit quaternion, v = e3 */
+int kr_state_init_straight(kr_handle* h, int64_t B, void* state, int dtype, void* stream);
+/* y_fm[B][19][N], z_fm[B][6][N] (reference layout) <-> state[B][N][KR_SLOTS] */
+int kr_state_pack(kr_handle* h, int64_t B, const void* y_fm, const void* z_fm, void* state, int dtype, void* stream);
+int kr_state_unpack(kr_handle* h, int64_t B, const void* state, void* y_fm, void* z_fm, int dtype, void* stream);
+/* rows [y; z; yh; zh] of one knode.simulate trajectory entry (knode.py:96):
+ * out[B][50][N] from state (step k) and the two states before it */
+int kr_state_unpack50(kr_handle* h, int64_t B, const void* state, const void* state_m1, const void* state_m2,
+                      void* out, int dtype, void* stream);
+/* tip[B][3] = p of the last grid point */
+int kr_state_tip(kr_handle* h, int64_t B, const void* state, void* tip, int dtype, void* stream);
+
+/* ---- shooting residual ------------------------------------------------- */
+/* CosseratRod.getResidualEuler / getResidualRK4 (cosserat_ode.py:188-255):
+ * one sweep from the guessed base wrench G[B][6]; writes the swept state into
+ * state_next (the reference mutates y, z in place) and r[B][6] =
+ * [F_tip - n(L), M_tip - m(L)].  History terms come from state_cur, state_prev
+ * (knode.py:74-75).  tensions[B][4].
+ * hist_is_explicit != 0: state_cur holds the history terms yh, zh themselves
+ * (packed like a state) and state_prev is ignored - the calling convention of
+ * the reference method, which receives yh, zh as arguments. */
+int kr_residual_batch(kr_handle* h, int64_t B, int scheme, const void* G, const void* state_prev,
+                      const void* state_cur, void* state_next, const void* tensions, void* r, int use_nn,
+                      int hist_is_explicit, int dtype, void* stream);
+
+/* ---- one implicit time step -------------------------------------------- */
+/* Body of the loop in knode.simulate (knode.py:70-100) for B rods: BDF2
+ * history from (state_cur, state_prev), shooting solve for G (Newton with a
+ * forward-difference Jacobian instead of MINPACK hybrd; same root), final
+ * swept state into state_next.  G[B][6] is read as the initial guess and
+ * overwritten with the solution.  tol: stop when |dG|_inf <= tol*max(1,|G|_inf)
+ * (<=0 selects 1e-10 for f64, 1e-5 for f32); maxit <= 0 selects 30.
+ * status[B], iters[B] (int32) may be NULL. */
+int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, const void* state_cur,
+                  void* state_next, void* G, const void* tensions, double tol, int maxit, int32_t* status,
+                  int32_t* iters, int use_nn, int dtype, void* stream);
+
+/* T steps of the above in one call.  ctl[B][T][4]; states[(T+1)][B][N][KR_SLOTS]
+ * with states[0] the initial condition (e.g. kr_state_init_straight) - step t
+ * writes states[t+1]; if ring != 0, `states` holds only 3 slots used
+ * cyclically (slot (t+1)%3) for tip-only runs.  tip[B][T][3] may be NULL.
+ * status[B][T] may be NULL.  Replaces knode.simulate (knode.py:55-102). */
+int kr_simulate_batch(kr_handle* h, int64_t B, int64_t T, int scheme, const void* ctl, void* states, int ring,
+                      void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn, int dtype,
+                      void* stream);
+
+/* ---- KNODE one-step-ahead training path -------------------------------- */
+/* CosseratRodTorch.parallelGetNextSegmentEuler (cosserat_ode_torch.py:401-437)
+ * and, with idx = 1..N-1, getNextSegmentEuler (:370-399), plus the four-term
+ * loss of physics_train.py:252-259.  Defined in round 1 as three calls so that
+ * torch autograd only sees dense tensors:
+ *
+ * kr_next_segment_physics: for every (s, k): j = idx[k]-1, row = s*K+k
+ *    x[row][in_pad]   MLP input  [y_j, z_phys, tf] (or the 53-wide history form), zero padded
+ *    base[row][25]    [y_j + ds*ys_phys, z_phys]    (prediction without the MLP)
+ * Gs[S][25][N], yh[S][19][N], zh[S][6][N] feature-major (reference layout),
+ * tensions[S][4], idx[K] int32 on device. f32 or f64. */
+int kr_next_segment_physics(kr_handle* h, int64_t S, int K, const void* Gs, const void* yh, const void* zh,
+                            const void* tensions, const int32_t* idx, void* x, int in_pad, void* base,
+                            int dtype, void* stream);
+
+/* Two-layer-or-deeper MLP forward over Q rows on the matrix cores (exact-f32
+ * MFMA): out[Q][25] = MLP(x[Q][in_pad]); keeps the pre-activations the
+ * backward pass needs in `ws` (kr_mlp_ws_bytes).  Weights are the caller's
+ * device tensors (torch parameters), row-major like nn.Linear. */
+size_t kr_mlp_ws_bytes(int n_layers, const int32_t* dims, int64_t Q);
+int kr_mlp_forward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts,
+                   const float* const* W, const float* const* b, const float* x, int in_pad, float* out,
+                   void* ws, void* stream);
+/* dW[k], db[k] (+=0: overwritten) from dout[Q][25] */
+int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts,
+                    const float* const* W, const float* x, int in_pad, const float* dout, const void* ws,
+                    float* const* dW, float* const* db, void* stream);
+
+/* pred[row][25] = base + [ds*out[:19], out[19:]]; loss terms of
+ * physics_train.py:252-259 against target[S][25][N] at columns idx[k]
+ * (z rows against idx[k]-1); writes pred, the scalar loss (sum over s of the
+ * four mean-squared terms, divided by `denom`) and dout[row][25] = dloss/dout. */
+int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const float* out, const float* target,
+                    const int32_t* idx, double denom, float* pred, float* loss, float* dout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNODE_ROD_H */

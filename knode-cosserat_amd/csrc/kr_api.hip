@@ -1,0 +1,470 @@
+// kr_api.hip - the extern "C" surface of libknode_rod.so (include/knode_rod.h):
+// handle management, parameter derivation (reference cosserat_ode.py:58-78),
+// presets (knode.py:6-53), MLP packing and the dtype dispatch of every call.
+#include <cmath>
+#include <cstring>
+
+#include "kr_internal.hpp"
+
+namespace kr {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return KR_E_HIP;
+}
+
+int ensure_ws(kr_handle* h, size_t bytes) {
+  if (bytes <= h->ws_bytes) return KR_OK;
+  if (h->ws) {
+    KR_HIP(hipDeviceSynchronize());
+    KR_HIP(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+  }
+  size_t want = bytes + bytes / 4;
+  KR_HIP(hipMalloc(&h->ws, want));
+  h->ws_bytes = want;
+  return KR_OK;
+}
+
+static void mat3_diag(double* m, double a, double b, double c) {
+  for (int i = 0; i < 9; ++i) m[i] = 0;
+  m[0] = a; m[4] = b; m[8] = c;
+}
+static bool inv3(const double* a, double* o) {
+  const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  if (det == 0.0 || !std::isfinite(det)) return false;
+  const double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+  o[3] = c01 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+  o[6] = c02 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+  return true;
+}
+static bool is_diag(const double* m) {
+  return m[1] == 0 && m[2] == 0 && m[3] == 0 && m[5] == 0 && m[6] == 0 && m[7] == 0;
+}
+
+// cosserat_ode.py:58-78
+static int derive(const kr_params& p, kr_derived& d) {
+  if (p.N < 2) { set_error("N must be >= 2"); return KR_E_ARG; }
+  if (!(p.del_t > 0) || !(p.L > 0) || !(p.r > 0)) { set_error("L, r, del_t must be positive"); return KR_E_ARG; }
+  const double pi = 3.14159265358979323846;
+  d.A = pi * p.r * p.r;
+  d.G = p.E / (2 * (1 + 0.3));
+  d.ds = p.L / (p.N - 1);
+  const double r4 = p.r * p.r * p.r * p.r;
+  mat3_diag(d.J, pi * r4 / 4, pi * r4 / 4, pi * r4 / 2);
+  mat3_diag(d.Kse, d.G * d.A, d.G * d.A, p.E * d.A);
+  mat3_diag(d.Kbt, p.E * d.J[0], p.E * d.J[4], d.G * d.J[8]);
+  d.c0 = 1.5 / p.del_t;
+  d.c1 = -2.0 / p.del_t;
+  d.c2 = 0.5 / p.del_t;
+  double t[9];
+  for (int i = 0; i < 9; ++i) t[i] = d.Kse[i] + d.c0 * p.Bse[i];
+  if (!inv3(t, d.Kse_plus_c0_Bse_inv)) { set_error("Kse + c0*Bse is singular"); return KR_E_ARG; }
+  for (int i = 0; i < 9; ++i) t[i] = d.Kbt[i] + d.c0 * p.Bbt[i];
+  if (!inv3(t, d.Kbt_plus_c0_Bbt_inv)) { set_error("Kbt + c0*Bbt is singular"); return KR_E_ARG; }
+  for (int i = 0; i < 3; ++i)
+    d.Kse_vstar[i] = d.Kse[3 * i] * p.vstar[0] + d.Kse[3 * i + 1] * p.vstar[1] + d.Kse[3 * i + 2] * p.vstar[2];
+  d.rhoA = p.rho * d.A;
+  for (int i = 0; i < 3; ++i) d.rhoAg[i] = d.rhoA * p.g[i];
+  for (int i = 0; i < 9; ++i) d.rhoJ[i] = p.rho * d.J[i];
+  return KR_OK;
+}
+
+template <typename T>
+static void fill_consts(const kr_params& p, const kr_derived& d, RodConst<T>& c) {
+  c.c0 = (T)d.c0; c.c1 = (T)d.c1; c.c2 = (T)d.c2; c.ds = (T)d.ds; c.rhoA = (T)d.rhoA;
+  for (int i = 0; i < 9; ++i) {
+    c.Ksei[i] = (T)d.Kse_plus_c0_Bse_inv[i];
+    c.Kbti[i] = (T)d.Kbt_plus_c0_Bbt_inv[i];
+    c.Bse[i] = (T)p.Bse[i];
+    c.Bbt[i] = (T)p.Bbt[i];
+    c.rhoJ[i] = (T)d.rhoJ[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    c.Kse_vstar[i] = (T)d.Kse_vstar[i];
+    c.rhoAg[i] = (T)d.rhoAg[i];
+    c.C[i] = (T)p.C[i];
+    c.Ftip[i] = (T)p.F_tip[i];
+    c.Mtip[i] = (T)p.M_tip[i];
+    c.p0[i] = (T)p.p0[i];
+    c.q0[i] = (T)p.q0[i];
+    c.w0[i] = (T)p.w0[i];
+  }
+  for (int i = 0; i < 4; ++i) c.h0[i] = (T)p.h0[i];
+  for (int i = 0; i < 12; ++i) c.tdirs[i] = (T)p.tendon_dirs[i];
+  c.N = p.N;
+  c.diag = is_diag(d.Kse_plus_c0_Bse_inv) && is_diag(d.Kbt_plus_c0_Bbt_inv) && is_diag(p.Bse) && is_diag(p.Bbt) &&
+           is_diag(d.rhoJ);
+}
+
+static void free_mlp(kr_handle* h) {
+  for (void* p : h->mlp_allocs) (void)hipFree(p);
+  h->mlp_allocs.clear();
+  h->mlp_f = MlpDev<float>{};
+  h->mlp_d = MlpDev<double>{};
+}
+
+}  // namespace kr
+
+using namespace kr;
+
+#define KR_CHECK_H(h)                      \
+  if (!(h)) {                              \
+    set_error("null handle");              \
+    return KR_E_ARG;                       \
+  }
+#define KR_CHECK_PTR(p)                            \
+  if (!(p)) {                                      \
+    set_error("null pointer argument: " #p);       \
+    return KR_E_ARG;                               \
+  }
+#define KR_CHECK_DTYPE(dt)                         \
+  if ((dt) != KR_F32 && (dt) != KR_F64) {          \
+    set_error("dtype must be KR_F32 or KR_F64");   \
+    return KR_E_ARG;                               \
+  }
+
+template <typename T>
+static StepArgs<T> make_args(const kr_handle* h, int64_t B, const void* prev, const void* cur, void* next, void* G, const void* tens,
+                             int64_t tens_stride, double tol, int maxit) {
+  StepArgs<T> a{};
+  a.B = B;
+  a.prev = (const T*)prev; a.cur = (const T*)cur; a.next = (T*)next;
+  a.G = (T*)G;
+  a.tens = (const T*)tens; a.tens_stride = tens_stride;
+  const bool f64 = sizeof(T) == 8;
+  if (!(tol > 0)) tol = f64 ? 1e-10 : 1e-5;
+  a.tol = (T)tol;
+  a.tolA = (T)std::sqrt(tol);
+  a.fd_eps = f64 ? (T)1e-7 : (T)1e-3;
+  a.maxit = maxit > 0 ? maxit : 30;
+  a.mode = 0;
+  a.hc1 = (T)h->derived.c1; a.hc2 = (T)h->derived.c2;
+  a.st_stride = 1;
+  a.tip_stride = 3;
+  return a;
+}
+
+template <typename T>
+static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, const void* ctl, void* states, int ring,
+                         void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn, hipStream_t s) {
+  const size_t slot = (size_t)B * h->params.N * KR_SLOTS;
+  T* base = (T*)states;
+  for (int64_t t = 0; t < T_steps; ++t) {
+    // knode.py:65-66,76-77: before the first step y_prev = y
+    const int64_t ic = ring ? t % 3 : t;
+    const int64_t ip = t == 0 ? ic : (ring ? (t + 2) % 3 : t - 1);
+    const int64_t in = ring ? (t + 1) % 3 : t + 1;
+    auto a = make_args<T>(h, B, base + ip * slot, base + ic * slot, base + in * slot, G, (const T*)ctl + t * 4,
+                          T_steps * 4, tol, maxit);
+    if (tip) { a.tip = (T*)tip + t * 3; a.tip_stride = T_steps * 3; }
+    if (status) { a.status = status + t; a.st_stride = T_steps; }
+    int rc = launch_step<T>(h, scheme, use_nn, a, s);
+    if (rc) return rc;
+  }
+  return KR_OK;
+}
+
+extern "C" {
+
+const char* kr_last_error(void) { return g_err.c_str(); }
+int kr_version(void) { return 100; }
+
+int kr_default_params(kr_params* o) {
+  KR_CHECK_PTR(o);
+  std::memset(o, 0, sizeof(*o));
+  o->L = 0.4; o->N = 10; o->E = 109e9; o->r = 0.0012; o->rho = 8000.0;
+  o->vstar[2] = 1.0;
+  o->g[2] = -9.81;
+  o->Bbt[0] = o->Bbt[4] = o->Bbt[8] = 3e-2;
+  o->C[0] = o->C[1] = o->C[2] = 1e-4;
+  o->del_t = 0.005;
+  const double pi = 3.14159265358979323846;
+  const double th = pi / 4;  // pi / n_tendons
+  for (int k = 0; k < 4; ++k) {
+    o->tendon_dirs[3 * k + 0] = std::cos(th + k * pi / 2);
+    o->tendon_dirs[3 * k + 1] = std::sin(th + k * pi / 2);
+    o->tendon_dirs[3 * k + 2] = 0.0;
+  }
+  o->h0[0] = 1.0;
+  return KR_OK;
+}
+
+int kr_apply_preset(kr_params* p, const char* mod) {
+  KR_CHECK_PTR(p);
+  p->del_t = 0.05; p->L = 0.635; p->r = 0.003175; p->rho = 1411.6751; p->E = 2.757903e9;
+  double bbt = 3e-2;
+  const std::string m = mod ? mod : "";
+  if (m.empty() || m == "None") {
+  } else if (m == "noair") {
+    p->C[0] = p->C[1] = p->C[2] = 0;
+  } else if (m == "nsw") {
+    p->g[0] = p->g[1] = p->g[2] = 0;
+  } else if (m == "short") {
+    p->L = 0.4;
+  } else if (m == "damping") {
+    bbt = 0.2;
+  } else if (m == "dampstiff") {
+    bbt = 0.2; p->E = 10e9;
+  } else if (m == "lengthstiff") {
+    p->L = 0.4; p->E = 10e9;
+  } else if (m == "youngs") {
+    p->E = 10e9;
+  } else {
+    set_error("Unknown mod " + m);
+    return KR_E_ARG;
+  }
+  for (int i = 0; i < 9; ++i) p->Bbt[i] = 0;
+  p->Bbt[0] = p->Bbt[4] = p->Bbt[8] = bbt;
+  return KR_OK;
+}
+
+int kr_set_params(kr_handle* h, const kr_params* p) {
+  KR_CHECK_H(h);
+  KR_CHECK_PTR(p);
+  kr_derived d{};
+  int rc = derive(*p, d);
+  if (rc) return rc;
+  h->params = *p;
+  h->derived = d;
+  fill_consts(*p, d, h->cf);
+  fill_consts(*p, d, h->cd);
+  return KR_OK;
+}
+
+int kr_create(const kr_params* p, int device, kr_handle** out) {
+  KR_CHECK_PTR(p);
+  KR_CHECK_PTR(out);
+  int ndev = 0;
+  KR_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    set_error("no such HIP device");
+    return KR_E_ARG;
+  }
+  KR_HIP(hipSetDevice(device));
+  kr_handle* h = new kr_handle();
+  h->device = device;
+  int rc = kr_set_params(h, p);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+    h->lds_limit = lds;
+  *out = h;
+  return KR_OK;
+}
+
+int kr_destroy(kr_handle* h) {
+  if (!h) return KR_OK;
+  free_mlp(h);
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+  return KR_OK;
+}
+
+int kr_get_derived(const kr_handle* h, kr_derived* out) {
+  KR_CHECK_H(h);
+  KR_CHECK_PTR(out);
+  *out = h->derived;
+  return KR_OK;
+}
+
+int kr_derive(const kr_params* p, kr_derived* out) {
+  KR_CHECK_PTR(p);
+  KR_CHECK_PTR(out);
+  return derive(*p, *out);
+}
+
+int kr_mlp_eval_batch(kr_handle* h, int64_t Q, const void* x, void* out, int dtype, void* stream) {
+  KR_CHECK_H(h);
+  KR_CHECK_DTYPE(dtype);
+  if (Q < 0) { set_error("Q < 0"); return KR_E_ARG; }
+  if (Q == 0) return KR_OK;
+  KR_CHECK_PTR(x); KR_CHECK_PTR(out);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == KR_F32 ? launch_mlp_eval<float>(h, Q, (const float*)x, (float*)out, s)
+                         : launch_mlp_eval<double>(h, Q, (const double*)x, (double*)out, s);
+}
+
+int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
+               const float* const* b, int src_on_device, void* stream) {
+  KR_CHECK_H(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KR_HIP(hipStreamSynchronize(s));
+  free_mlp(h);
+  if (n_layers == 0) return KR_OK;
+  if (n_layers < 0 || n_layers > KR_MAX_LAYERS) {
+    set_error("n_layers out of range");
+    return KR_E_ARG;
+  }
+  KR_CHECK_PTR(dims); KR_CHECK_PTR(acts); KR_CHECK_PTR(W); KR_CHECK_PTR(b);
+  const int want_in = h->params.nn_input_history ? 53 : 28;
+  if (dims[0] != want_in || dims[n_layers] != 25) {
+    set_error("MLP must map " + std::to_string(want_in) + " -> 25 (cosserat_ode_torch.py:60-62)");
+    return KR_E_ARG;
+  }
+  MlpDev<float> mf{};
+  MlpDev<double> md{};
+  mf.n_layers = md.n_layers = n_layers;
+  int maxd = dims[0];
+  for (int k = 0; k <= n_layers; ++k) {
+    if (dims[k] <= 0) { set_error("bad layer width"); return KR_E_ARG; }
+    mf.dims[k] = md.dims[k] = dims[k];
+  }
+  for (int k = 0; k < n_layers; ++k) {
+    if (acts[k] < KR_ACT_NONE || acts[k] > KR_ACT_ELU) { set_error("bad activation code"); return KR_E_ARG; }
+    const int in = dims[k], out = dims[k + 1];
+    const int opad = (out + 15) / 16 * 16;
+    if (opad > maxd) maxd = opad;
+    mf.out_pad[k] = md.out_pad[k] = opad;
+    mf.acts[k] = md.acts[k] = acts[k];
+    std::vector<float> hw((size_t)in * out), hb(out);
+    if (src_on_device) {
+      KR_HIP(hipMemcpy(hw.data(), W[k], hw.size() * sizeof(float), hipMemcpyDeviceToHost));
+      KR_HIP(hipMemcpy(hb.data(), b[k], hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+      std::memcpy(hw.data(), W[k], hw.size() * sizeof(float));
+      std::memcpy(hb.data(), b[k], hb.size() * sizeof(float));
+    }
+    std::vector<float> wt_f((size_t)in * opad, 0.f), b_f(opad, 0.f);
+    std::vector<double> wt_d((size_t)in * opad, 0.0), b_d(opad, 0.0);
+    for (int o = 0; o < out; ++o) {
+      b_f[o] = hb[o];
+      b_d[o] = (double)hb[o];
+      for (int i = 0; i < in; ++i) {
+        wt_f[(size_t)i * opad + o] = hw[(size_t)o * in + i];
+        wt_d[(size_t)i * opad + o] = (double)hw[(size_t)o * in + i];
+      }
+    }
+    void *dwf, *dbf, *dwd, *dbd;
+    KR_HIP(hipMalloc(&dwf, wt_f.size() * sizeof(float)));  h->mlp_allocs.push_back(dwf);
+    KR_HIP(hipMalloc(&dbf, b_f.size() * sizeof(float)));   h->mlp_allocs.push_back(dbf);
+    KR_HIP(hipMalloc(&dwd, wt_d.size() * sizeof(double))); h->mlp_allocs.push_back(dwd);
+    KR_HIP(hipMalloc(&dbd, b_d.size() * sizeof(double)));  h->mlp_allocs.push_back(dbd);
+    KR_HIP(hipMemcpy(dwf, wt_f.data(), wt_f.size() * sizeof(float), hipMemcpyHostToDevice));
+    KR_HIP(hipMemcpy(dbf, b_f.data(), b_f.size() * sizeof(float), hipMemcpyHostToDevice));
+    KR_HIP(hipMemcpy(dwd, wt_d.data(), wt_d.size() * sizeof(double), hipMemcpyHostToDevice));
+    KR_HIP(hipMemcpy(dbd, b_d.data(), b_d.size() * sizeof(double), hipMemcpyHostToDevice));
+    mf.Wt[k] = static_cast<float*>(dwf);  mf.b[k] = static_cast<float*>(dbf);
+    md.Wt[k] = static_cast<double*>(dwd); md.b[k] = static_cast<double*>(dbd);
+  }
+  mf.max_dim = md.max_dim = maxd;
+  h->mlp_f = mf;
+  h->mlp_d = md;
+  return KR_OK;
+}
+
+int kr_ode_batch(kr_handle* h, int64_t Q, const void* y, const void* yh, const void* zh, const void* tf, void* dys,
+                 void* z, int use_nn, int dtype, void* stream) {
+  KR_CHECK_H(h);
+  KR_CHECK_DTYPE(dtype);
+  if (Q < 0) { set_error("Q < 0"); return KR_E_ARG; }
+  if (Q == 0) return KR_OK;
+  KR_CHECK_PTR(y); KR_CHECK_PTR(yh); KR_CHECK_PTR(zh); KR_CHECK_PTR(tf); KR_CHECK_PTR(dys); KR_CHECK_PTR(z);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == KR_F32)
+    return launch_ode_batch<float>(h, Q, (const float*)y, (const float*)yh, (const float*)zh, (const float*)tf,
+                                   (float*)dys, (float*)z, use_nn, s);
+  return launch_ode_batch<double>(h, Q, (const double*)y, (const double*)yh, (const double*)zh, (const double*)tf,
+                                  (double*)dys, (double*)z, use_nn, s);
+}
+
+#define KR_BATCH_PROLOGUE(B)                       \
+  KR_CHECK_H(h);                                   \
+  KR_CHECK_DTYPE(dtype);                           \
+  if ((B) < 0) { set_error("B < 0"); return KR_E_ARG; } \
+  if ((B) == 0) return KR_OK;                      \
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+int kr_state_init_straight(kr_handle* h, int64_t B, void* state, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(state);
+  return dtype == KR_F32 ? launch_init_straight<float>(h, B, (float*)state, s)
+                         : launch_init_straight<double>(h, B, (double*)state, s);
+}
+int kr_state_pack(kr_handle* h, int64_t B, const void* y_fm, const void* z_fm, void* state, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(y_fm); KR_CHECK_PTR(z_fm); KR_CHECK_PTR(state);
+  return dtype == KR_F32 ? launch_pack<float>(h, B, (const float*)y_fm, (const float*)z_fm, (float*)state, s)
+                         : launch_pack<double>(h, B, (const double*)y_fm, (const double*)z_fm, (double*)state, s);
+}
+int kr_state_unpack(kr_handle* h, int64_t B, const void* state, void* y_fm, void* z_fm, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(y_fm); KR_CHECK_PTR(z_fm); KR_CHECK_PTR(state);
+  return dtype == KR_F32 ? launch_unpack<float>(h, B, (const float*)state, (float*)y_fm, (float*)z_fm, s)
+                         : launch_unpack<double>(h, B, (const double*)state, (double*)y_fm, (double*)z_fm, s);
+}
+int kr_state_unpack50(kr_handle* h, int64_t B, const void* state, const void* m1, const void* m2, void* out, int dtype,
+                      void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(state); KR_CHECK_PTR(m1); KR_CHECK_PTR(m2); KR_CHECK_PTR(out);
+  return dtype == KR_F32
+             ? launch_unpack50<float>(h, B, (const float*)state, (const float*)m1, (const float*)m2, (float*)out, s)
+             : launch_unpack50<double>(h, B, (const double*)state, (const double*)m1, (const double*)m2, (double*)out, s);
+}
+int kr_state_tip(kr_handle* h, int64_t B, const void* state, void* tip, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(state); KR_CHECK_PTR(tip);
+  return dtype == KR_F32 ? launch_tip<float>(h, B, (const float*)state, (float*)tip, s)
+                         : launch_tip<double>(h, B, (const double*)state, (double*)tip, s);
+}
+
+int kr_residual_batch(kr_handle* h, int64_t B, int scheme, const void* G, const void* state_prev,
+                      const void* state_cur, void* state_next, const void* tensions, void* r, int use_nn,
+                      int hist_is_explicit, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(G); KR_CHECK_PTR(state_cur); KR_CHECK_PTR(state_next);
+  KR_CHECK_PTR(tensions); KR_CHECK_PTR(r);
+  if (hist_is_explicit) state_prev = state_cur;
+  KR_CHECK_PTR(state_prev);
+  if (dtype == KR_F32) {
+    auto a = make_args<float>(h, B, state_prev, state_cur, state_next, const_cast<void*>(G), tensions, 4, 0, 0);
+    a.mode = 1; a.r_out = (float*)r;
+    if (hist_is_explicit) { a.hc1 = 1.f; a.hc2 = 0.f; }
+    return launch_step<float>(h, scheme, use_nn, a, s);
+  }
+  auto a = make_args<double>(h, B, state_prev, state_cur, state_next, const_cast<void*>(G), tensions, 4, 0, 0);
+  a.mode = 1; a.r_out = (double*)r;
+  if (hist_is_explicit) { a.hc1 = 1.0; a.hc2 = 0.0; }
+  return launch_step<double>(h, scheme, use_nn, a, s);
+}
+
+int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, const void* state_cur,
+                  void* state_next, void* G, const void* tensions, double tol, int maxit, int32_t* status,
+                  int32_t* iters, int use_nn, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(G); KR_CHECK_PTR(state_prev); KR_CHECK_PTR(state_cur); KR_CHECK_PTR(state_next);
+  KR_CHECK_PTR(tensions);
+  if (state_next == state_cur || state_next == state_prev) {
+    set_error("state_next must not alias state_cur / state_prev");
+    return KR_E_ARG;
+  }
+  if (dtype == KR_F32) {
+    auto a = make_args<float>(h, B, state_prev, state_cur, state_next, G, tensions, 4, tol, maxit);
+    a.status = status; a.iters = iters;
+    return launch_step<float>(h, scheme, use_nn, a, s);
+  }
+  auto a = make_args<double>(h, B, state_prev, state_cur, state_next, G, tensions, 4, tol, maxit);
+  a.status = status; a.iters = iters;
+  return launch_step<double>(h, scheme, use_nn, a, s);
+}
+
+int kr_simulate_batch(kr_handle* h, int64_t B, int64_t T, int scheme, const void* ctl, void* states, int ring, void* G,
+                      void* tip, double tol, int maxit, int32_t* status, int use_nn, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  if (T < 0) { set_error("T < 0"); return KR_E_ARG; }
+  if (T == 0) return KR_OK;
+  KR_CHECK_PTR(ctl); KR_CHECK_PTR(states); KR_CHECK_PTR(G);
+  return dtype == KR_F32
+             ? simulate_impl<float>(h, B, T, scheme, ctl, states, ring, G, tip, tol, maxit, status, use_nn, s)
+             : simulate_impl<double>(h, B, T, scheme, ctl, states, ring, G, tip, tol, maxit, status, use_nn, s);
+}
+
+}  // extern "C"

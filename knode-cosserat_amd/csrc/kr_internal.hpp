@@ -1,0 +1,116 @@
+// kr_internal.hpp - host-side handle and launch declarations shared by the
+// translation units of libknode_rod.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/knode_rod.h"
+#include "rod_device.hpp"
+
+namespace kr {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+#define KR_HIP(expr)                                   \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return kr::hip_fail(_e, #expr); \
+  } while (0)
+
+// Packed MLP on the device: per layer a transposed weight matrix
+// Wt[in][out_pad] (out_pad = out rounded up to 16) and bias b[out_pad], in
+// both precisions, so that for a fixed input unit the weights of 16 output
+// units are contiguous and can be fetched with scalar loads.
+template <typename T>
+struct MlpDev {
+  int n_layers;
+  int dims[KR_MAX_LAYERS + 1];
+  int out_pad[KR_MAX_LAYERS];
+  int acts[KR_MAX_LAYERS];
+  const T* Wt[KR_MAX_LAYERS];
+  const T* b[KR_MAX_LAYERS];
+  int max_dim;  // widest activation vector (incl. input and output)
+};
+
+}  // namespace kr
+
+struct kr_handle {
+  int device = 0;
+  kr_params params{};
+  kr_derived derived{};
+  kr::RodConst<float> cf{};
+  kr::RodConst<double> cd{};
+  // MLP
+  kr::MlpDev<float> mlp_f{};
+  kr::MlpDev<double> mlp_d{};
+  std::vector<void*> mlp_allocs;
+  // lazily grown scratch (history fallback, MLP activation spill)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  int lds_limit = 160 * 1024;
+};
+
+namespace kr {
+
+int ensure_ws(kr_handle* h, size_t bytes);
+
+template <typename T>
+inline const RodConst<T>& consts(kr_handle* h);
+template <>
+inline const RodConst<float>& consts<float>(kr_handle* h) { return h->cf; }
+template <>
+inline const RodConst<double>& consts<double>(kr_handle* h) { return h->cd; }
+template <typename T>
+inline const MlpDev<T>& mlpdev(kr_handle* h);
+template <>
+inline const MlpDev<float>& mlpdev<float>(kr_handle* h) { return h->mlp_f; }
+template <>
+inline const MlpDev<double>& mlpdev<double>(kr_handle* h) { return h->mlp_d; }
+
+// kr_sim.hip
+template <typename T>
+int launch_init_straight(kr_handle* h, int64_t B, T* state, hipStream_t s);
+template <typename T>
+int launch_pack(kr_handle* h, int64_t B, const T* y_fm, const T* z_fm, T* state, hipStream_t s);
+template <typename T>
+int launch_unpack(kr_handle* h, int64_t B, const T* state, T* y_fm, T* z_fm, hipStream_t s);
+template <typename T>
+int launch_unpack50(kr_handle* h, int64_t B, const T* st, const T* m1, const T* m2, T* out, hipStream_t s);
+template <typename T>
+int launch_tip(kr_handle* h, int64_t B, const T* state, T* tip, hipStream_t s);
+
+template <typename T>
+struct StepArgs {
+  int64_t B;
+  const T* prev;
+  const T* cur;
+  T* next;
+  T* G;             // [B][6] in/out (residual mode: in only)
+  const T* tens;    // tensions of rod b at tens[b*tens_stride .. +4]
+  int64_t tens_stride;
+  T* r_out;         // residual mode: [B][6]
+  T* tip;           // optional: tip[b*tip_stride .. +3]
+  int64_t tip_stride;
+  int32_t* status;  // optional: status[b*st_stride]
+  int32_t* iters;
+  int64_t st_stride;
+  T* hist_ws;       // global history fallback [B][N][HS]
+  T* act_ws;        // MLP activation spill (global) or nullptr
+  T tol, tolA, fd_eps;
+  T hc1, hc2;       // history = hc1*cur + hc2*prev (c1, c2 of BDF2, or 1, 0 for explicit history)
+  int maxit;
+  int mode;         // 0 = Newton step, 1 = single residual sweep
+};
+template <typename T>
+int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s);
+
+// kr_ode.hip
+template <typename T>
+int launch_mlp_eval(kr_handle* h, int64_t Q, const T* x, T* out, hipStream_t s);
+template <typename T>
+int launch_ode_batch(kr_handle* h, int64_t Q, const T* y, const T* yh, const T* zh, const T* tf, T* dys, T* z,
+                     int use_nn, hipStream_t s);
+
+}  // namespace kr

@@ -1,0 +1,3 @@
+// double instantiation of the simulation kernels
+#define KR_SIM_T double
+#include "kr_sim_impl.hpp"

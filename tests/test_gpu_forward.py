@@ -1,0 +1,349 @@
+"""GPU parity tests of the forward path (run with ``-m gpu`` on the MI355X box).
+
+Everything goes through the reference-shaped Python surface
+(``cosserat_ode.CosseratRod``, ``knode.setup_robot`` / ``simulate``), i.e. through
+the C ABI of libknode_rod.so, and is compared with
+
+  * the golden vectors the reference produced (tests/golden/*.npz), and
+  * the CPU oracle (oracle/cosserat_oracle.py) on seeded inputs.
+
+Tolerances: fp64 results are compared at 1e-9..1e-12 relative L2 (the reference
+itself only converges its shooting solve to xtol=1.5e-8); the contract of
+BASELINE.json is tip-trajectory relative L2 <= 1e-5, which is what the fp32
+tests assert.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+MODS = ["default", None, "noair", "nsw", "short", "damping", "dampstiff", "lengthstiff", "youngs"]
+NN = ["elu64", "hist64", "tanh6464", "softplus6464", "relu6464", "elu6464"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def make_robot(mod, N, use_fsolve=True):
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot
+    r = CosseratRod(use_fsolve=use_fsolve)
+    if mod != "default":
+        setup_robot(r, mod)
+    r.N = N
+    r.compute_intermediate_terms()
+    return r
+
+
+def inject(robot, mlp):
+    """What physics_train.py:104-110 does, with plain strings standing in for the torch modules
+    (the reference only ever looks at str(layer))."""
+    import cosserat_oracle as orc
+    names = {orc.ACT_TANH: "Tanh()", orc.ACT_SOFTPLUS: "Softplus(beta=1.0, threshold=20.0)",
+             orc.ACT_RELU: "ReLU()", orc.ACT_ELU: "ELU(alpha=1.0)"}
+    model, params = [], []
+    for W, b, a in zip(mlp.weights, mlp.biases, mlp.acts):
+        model.append(f"Linear(in_features={W.shape[1]}, out_features={W.shape[0]}, bias=True)")
+        params += [W, b]
+        if a != orc.ACT_NONE:
+            model.append(names[a])
+    robot.nn_model = model
+    robot.param_ls = params
+    robot.nn_path = "whatever"
+    robot.nn_input_history = mlp.history
+
+
+# ---------------------------------------------------------------------------
+# K1: batched ODE
+# ---------------------------------------------------------------------------
+def _ode_rows_gpu(torch, robot, g, dtype):
+    dev = "cuda:0"
+    h = robot._native()
+    tf = g["tensions"] @ robot.tendon_dirs
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev).to(dtype).contiguous()
+    dys, z = h.ode_batch(t(g["y"]), t(g["yh"]), t(g["zh"]), t(tf), use_nn=robot._use_nn)
+    return torch.cat([dys, z], 1).cpu().numpy()
+
+
+@pytest.mark.parametrize("mod", MODS)
+def test_ode_batch_presets_f64(torch_cuda, mod):
+    g = load_golden("ode_kat")
+    got = _ode_rows_gpu(torch_cuda, make_robot(mod, 10), g, torch_cuda.float64)
+    ref = g[f"phys_{mod}"]
+    assert rel_l2(got, ref) < 1e-13
+    assert np.max(np.abs(got - ref) / (np.abs(ref) + 1e-9 * np.abs(ref).max())) < 1e-8
+
+
+@pytest.mark.parametrize("name", NN)
+def test_ode_batch_mlp_f64(torch_cuda, name):
+    import cosserat_oracle as orc
+    g = load_golden("ode_kat")
+    r = make_robot(None, 10)
+    inject(r, orc.mlp_from_arrays(g, f"mlp_{name}"))
+    got = _ode_rows_gpu(torch_cuda, r, g, torch_cuda.float64)
+    assert rel_l2(got, g[f"nn_{name}"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["elu64", "hist64", "elu6464"])
+@pytest.mark.parametrize("use_nn", [0, 1])
+def test_ode_batch_f32_vs_torch_twin(torch_cuda, name, use_nn):
+    """fp32 kernel against CosseratRodTorch.ODE_parallel / ODE outputs."""
+    import cosserat_oracle as orc
+    g = load_golden("ode_kat")
+    gt = load_golden("ode_torch_kat")
+    r = make_robot(None, 10)
+    if use_nn:
+        inject(r, orc.mlp_from_arrays(g, f"mlp_{name}"))
+    got = _ode_rows_gpu(torch_cuda, r, g, torch_cuda.float32)
+    ref = gt[f"par_{name}_{use_nn}"]
+    # the two fp32 statements of the reference agree with each other to ~1e-6; ask the same of ours
+    scale = np.abs(ref).max(axis=0, keepdims=True)
+    assert np.max(np.abs(got - ref) / scale) < 5e-5
+    assert rel_l2(got, ref) < 2e-6
+
+
+def test_ode_single_row_method(torch_cuda):
+    g = load_golden("ode_kat")
+    r = make_robot(None, 10)
+    i = 7
+    ys, z = r.ODE(g["y"][i], g["yh"][i], g["zh"][i], g["tensions"][i] @ r.tendon_dirs)
+    assert ys.shape == (19,) and z.shape == (6,)
+    assert rel_l2(np.concatenate([ys, z]), g["phys_None"][i]) < 1e-13
+
+
+def test_ode_ragged_sizes(torch_cuda):
+    """Q not a multiple of the tile, Q = 1, Q = 0."""
+    torch = torch_cuda
+    g = load_golden("ode_kat")
+    r = make_robot(None, 10)
+    h = r._native()
+    tf = g["tensions"] @ r.tendon_dirs
+    full = _ode_rows_gpu(torch, r, g, torch.float64)
+    for Q in (1, 47, 0):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a[:Q]), device="cuda:0").contiguous()
+        dys, z = h.ode_batch(t(g["y"]), t(g["yh"]), t(g["zh"]), t(tf))
+        assert dys.shape == (Q, 19)
+        if Q:
+            assert np.array_equal(torch.cat([dys, z], 1).cpu().numpy(), full[:Q])
+    # many tiles: replicate rows
+    reps = 700
+    big = lambda a: torch.as_tensor(np.tile(a, (reps, 1)), device="cuda:0").contiguous()
+    dys, z = h.ode_batch(big(g["y"]), big(g["yh"]), big(g["zh"]), big(tf))
+    out = torch.cat([dys, z], 1).cpu().numpy().reshape(reps, -1, 25)
+    assert np.array_equal(out[0], full) and np.array_equal(out[-1], full)
+
+
+# ---------------------------------------------------------------------------
+# shooting residuals
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["N10_None", "N20_None", "N100_None", "N10_default", "N40_default"])
+@pytest.mark.parametrize("scheme", ["euler", "rk4"])
+def test_residual_methods(torch_cuda, tag, scheme):
+    g = load_golden("residual_kat")
+    N = int(tag.split("_")[0][1:])
+    mod = tag.split("_")[1]
+    r = make_robot("default" if mod == "default" else None, N)
+    y0, z0, yp, zp = g[f"{tag}_y"], g[f"{tag}_z"], g[f"{tag}_yp"], g[f"{tag}_zp"]
+    yh = r.c1 * y0 + r.c2 * yp
+    zh = r.c1 * z0 + r.c2 * zp
+    yh_int = 0.5 * (yh[:, :-1] + yh[:, 1:])
+    zh_int = 0.5 * (zh[:, :-1] + zh[:, 1:])
+    r.tendon_tensions = g[f"{tag}_tens"]
+    fn = r.getResidualEuler if scheme == "euler" else r.getResidualRK4
+    for k, G in enumerate(g[f"{tag}_G"]):
+        ref_r, ref_y, ref_z = g[f"{tag}_{scheme}_r"][k], g[f"{tag}_{scheme}_y"][k], g[f"{tag}_{scheme}_z"][k]
+        if not np.all(np.isfinite(ref_r)):
+            continue  # the reference itself diverges (RK4 on a coarse grid)
+        y, z = y0.copy(), z0.copy()
+        res = fn(G, y, z, yh, yh_int, zh, zh_int)
+        assert rel_l2(y, ref_y) < 1e-10
+        assert rel_l2(z, ref_z) < 1e-10
+        assert np.allclose(res, ref_r, rtol=1e-8, atol=1e-10 * np.abs(ref_y[7:13]).max())
+        assert np.array_equal(z[:, -1], z0[:, -1])  # never written
+    # scalar form when use_fsolve is off (cosserat_ode.py:210-213)
+    r.use_fsolve = False
+    y, z = y0.copy(), z0.copy()
+    val = r.getResidualEuler(g[f"{tag}_G"][0], y, z, yh, yh_int, zh, zh_int)
+    assert np.isscalar(val) or np.ndim(val) == 0
+
+
+# ---------------------------------------------------------------------------
+# simulate
+# ---------------------------------------------------------------------------
+def test_simulate_cfg1(torch_cuda):
+    """BASELINE config 1: single rod, N=20, 200 steps, tensions [6,5,5,6]."""
+    from knode import simulate
+    g = load_golden("sim_cfg1")
+    r = make_robot(None, 20)
+    traj = simulate(r, g["ctl"])
+    assert traj.shape == (200, 50, 20) and traj.dtype == np.float64
+    assert rel_l2(traj[:, :3, -1], g["tip"]) < 1e-8
+    assert rel_l2(traj[::10, :25], g["every10"]) < 1e-7
+    assert rel_l2(traj[-1], g["last"]) < 1e-7
+
+
+def test_simulate_full50_layout(torch_cuda):
+    from knode import simulate
+    g = load_golden("sim_misc")
+    r = make_robot(None, 10)
+    traj = simulate(r, g["full50_ctl"])
+    ref = g["full50_traj"]
+    assert traj.shape == ref.shape
+    assert np.array_equal(traj[0], ref[0])  # initial entry incl. its [y;z;y;z] quirk
+    for lo, hi in ((0, 19), (19, 25), (25, 44), (44, 50)):
+        assert rel_l2(traj[:, lo:hi], ref[:, lo:hi]) < 1e-8
+
+
+@pytest.mark.parametrize("mod", MODS[2:] + ["default"])
+def test_simulate_presets(torch_cuda, mod):
+    from knode import simulate
+    g = load_golden("sim_misc")
+    r = make_robot(mod, 10)
+    traj = simulate(r, g[f"mod_{mod}_ctl"])
+    assert rel_l2(traj[:, :25], g[f"mod_{mod}_traj"]) < 1e-8
+
+
+@pytest.mark.parametrize("kind", ["step", "random"])
+def test_simulate_inputs(torch_cuda, kind):
+    from knode import simulate
+    g = load_golden("sim_misc")
+    r = make_robot(None, 10)
+    traj = simulate(r, g[f"{kind}_ctl"])
+    assert rel_l2(traj[:, :25], g[f"{kind}_traj"]) < 1e-8
+
+
+def test_simulate_n100_and_batch(torch_cuda):
+    from knode import simulate, simulate_batch
+    g = load_golden("sim_n100")
+    r = make_robot(None, 100)
+    traj = simulate(r, g["ctl"])
+    assert rel_l2(traj[:, :3, -1], g["tip"]) < 1e-8
+    assert rel_l2(traj[::10, :25], g["every10"]) < 1e-7
+    # cfg2-style batch: 6 rods with random phase / period, compared rod by rod
+    out = simulate_batch(r, g["batch_ctl"])
+    assert np.all(out["status"] == 0)
+    ref = g["batch_tip"]  # [B, T, 3], entry 0 = initial tip, entry t = after step t
+    got = out["traj"][:, : ref.shape[1], :3, -1]
+    for b in range(ref.shape[0]):
+        assert rel_l2(got[b], ref[b]) < 1e-8
+    # tip output of the kernel = tip of the stored state
+    assert np.array_equal(out["tip"], out["traj"][:, 1:, :3, -1])
+    # fp32 arithmetic stays inside the 1e-5 contract
+    out32 = simulate_batch(r, g["batch_ctl"], dtype="f32")
+    assert np.all(out32["status"] == 0)
+    for b in range(ref.shape[0]):
+        assert rel_l2(out32["traj"][b, : ref.shape[1], :3, -1], ref[b]) < 1e-5
+
+
+def test_simulate_n400(torch_cuda):
+    """N=400 does not fit the LDS history buffer: exercises the global-history path."""
+    from knode import simulate
+    g = load_golden("sim_n400")
+    r = make_robot(None, 400)
+    traj = simulate(r, g["ctl"])
+    assert rel_l2(traj[:, :3, -1], g["tip"]) < 1e-8
+    assert rel_l2(traj[-1, :25], g["last"]) < 1e-7
+
+
+def test_simulate_rk4(torch_cuda):
+    from knode import simulate_batch
+    g = load_golden("sim_misc")
+    r = make_robot(None, 40)
+    ctl = g["rk4_ctl"]
+    out = simulate_batch(r, ctl[None], scheme="rk4")
+    ref = g["rk4_traj"]  # [T, 25, N] entries 0..T-1
+    assert rel_l2(out["traj"][0, : ref.shape[0]], ref) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["elu64", "elu6464", "hist64"])
+def test_simulate_with_mlp(torch_cuda, name):
+    import cosserat_oracle as orc
+    from knode import simulate
+    g = load_golden("sim_nn")
+    r = make_robot(None, int(g[f"{name}_N"]))
+    inject(r, orc.mlp_from_arrays(g, f"mlp_{name}"))
+    traj = simulate(r, g[f"{name}_ctl"])
+    assert rel_l2(traj[:, :25], g[f"{name}_traj"]) < 1e-8
+
+
+def test_get_nn_output(torch_cuda):
+    import cosserat_oracle as orc
+    g = load_golden("ode_kat")
+    mlp = orc.mlp_from_arrays(g, "mlp_tanh6464")
+    r = make_robot(None, 10)
+    inject(r, mlp)
+    x = np.random.default_rng(0).standard_normal(28)
+    got = r.get_nn_output(x, r.nn_model, r.param_ls)
+    assert rel_l2(got, orc.mlp_eval(mlp, x)) < 1e-13
+
+
+# ---------------------------------------------------------------------------
+# full-size, size-independent properties (BASELINE: B=1024, N=100)
+# ---------------------------------------------------------------------------
+def test_full_size_properties(torch_cuda):
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    import krod_native as kn
+    r = make_robot(None, 100)
+    h = r._native()
+    B, T = 1024, 6
+    ctl = orc.batch_sine_controls(B, T, r.del_t, 1235)
+    dev = "cuda:0"
+    ctl_t = torch.as_tensor(ctl, device=dev).contiguous()
+    states = h.new_state(B, torch.float64, n_slots=T + 1)
+    h.init_straight(states[0])
+    G = torch.zeros((B, 6), dtype=torch.float64, device=dev)
+    status = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+    tip = torch.empty((B, T, 3), dtype=torch.float64, device=dev)
+    h.simulate(ctl_t, states, G, tip=tip, status=status)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0
+    # (1) the stored state is a root of the shooting residual: re-sweeping from the returned G
+    #     reproduces it bit for bit and leaves a tiny residual
+    nxt = h.new_state(B, torch.float64)
+    res = h.residual(G, states[T - 2], states[T - 1], nxt, ctl_t[:, T - 1].contiguous())
+    assert float(res.abs().max()) < 1e-8
+    assert torch.equal(nxt[..., :25], states[T][..., :25])
+    # (2) a rod's result does not depend on what else is in the batch (first 8 rods alone; one rod alone)
+    for nb in (8, 1, 13):
+        st2 = h.new_state(nb, torch.float64, n_slots=T + 1)
+        h.init_straight(st2[0])
+        G2 = torch.zeros((nb, 6), dtype=torch.float64, device=dev)
+        h.simulate(ctl_t[:nb].contiguous(), st2, G2)
+        assert torch.equal(st2[T], states[T][:nb])
+    # (3) oracle spot check on two rods of the big batch
+    D = orc.params_for(None, 100).derived()
+    for b in (0, 777):
+        tr = orc.simulate(D, np.vstack([ctl[b], ctl[b][-1:]]), solver="fsolve")
+        assert rel_l2(tip[b].cpu().numpy(), tr[1:, :3, -1]) < 1e-7
+    # (4) padding slots stay zero
+    assert float(states[T][..., 25:].abs().max()) == 0.0
+
+
+def test_error_paths(torch_cuda):
+    torch = torch_cuda
+    import krod_native as kn
+    from knode import setup_robot
+    r = make_robot(None, 10)
+    with pytest.raises(Exception):
+        setup_robot(r, "bogus")
+    with pytest.raises(Exception):
+        setup_robot(r, None, original=True)
+    h = r._native()
+    st = h.new_state(2, torch.float64, n_slots=3)
+    G = torch.zeros((2, 6), dtype=torch.float64, device="cuda:0")
+    tens = torch.ones((2, 4), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(kn.KrError):  # aliasing
+        h.step(st[0], st[1], st[1], G, tens)
+    with pytest.raises(kn.KrError):  # NN requested but never set
+        h.step(st[0], st[1], st[2], G, tens, use_nn=True)
+    with pytest.raises(kn.KrError):  # host tensor
+        h.step(st[0].cpu(), st[1], st[2], G, tens)
+    # empty batch is a no-op
+    h.step(st[0][:0], st[1][:0], st[2][:0], G[:0], tens[:0])
