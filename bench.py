@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rod-steps/s of the forward Cosserat-rod simulation.
+
+Workload (BASELINE.json metric "rod-steps/sec (N=100 segments, batch=1024)"):
+per GPU B=1024 rods, N=100 grid points, explicit-Euler shooting sweep inside an
+implicit BDF2 time step, fp64 (the reference's NumPy path is fp64), NN off,
+setup_robot(mod=None) parameters, per-rod sinusoidal tendon tensions
+(SURVEY 8d cfg3 inputs, default_rng(1235)).  One bench "step" = one time step of
+the whole batch = one launch of the shooting kernel (kr_step_batch through
+kr_simulate_batch, state resident in HBM: 3 packed-state slots used as a ring).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nodes-per-rod N] [--dtype f64|f32]
+
+N>1: launched by torch.distributed.run, one rank per GPU; rods are sharded
+(weak scaling, no data-path collective); the only collectives are the timing
+barrier and the MAX over ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "knode-cosserat_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_baseline(N, del_t_unused, sample_steps=24):
+    """Times the oracle (NumPy port of cosserat_ode.py + knode.simulate with
+    scipy fsolve - the reference's own execution model) on the host: one rod
+    per process on every available core, same workload definition."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import multiprocessing as mp
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    t0 = time.perf_counter()
+    single = _cpu_worker((N, 0, sample_steps))
+    t_single = time.perf_counter() - t0
+    with mp.get_context("fork").Pool(cores) as pool:
+        t0 = time.perf_counter()
+        tips = pool.map(_cpu_worker, [(N, b, sample_steps) for b in range(cores)])
+        t_all = time.perf_counter() - t0
+    return {
+        "value": round(cores * sample_steps / t_all, 3),
+        "unit": "rod-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{cores} rods x {sample_steps} steps of the bench workload (N={N}, fp64, fsolve shooting), "
+                  f"one rod per process",
+        "single_core_value": round(sample_steps / t_single, 3),
+    }, tips
+
+
+def _cpu_worker(args):
+    N, b, steps = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    import cosserat_oracle as orc
+    D = orc.params_for(None, N).derived()
+    ctl = orc.batch_sine_controls(max(b + 1, 16), steps, D.P.del_t, 1235)[b]
+    # the oracle mirrors knode.simulate: T controls -> T solves, last one dropped from the output
+    traj = orc.simulate(D, np.vstack([ctl, ctl[-1:]]), solver="fsolve")
+    return traj[1:, :3, -1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="rods per GPU")
+    ap.add_argument("--nodes-per-rod", type=int, default=100, help="N, grid points per rod")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import krod_native as kn
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    B, N, K, W = args.batch, args.nodes_per_rod, args.steps, args.warmup
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    esize = 8 if args.dtype == "f64" else 4
+
+    robot = CosseratRod(use_fsolve=True, device=local_rank)
+    setup_robot(robot)
+    robot.N = N
+    robot.compute_intermediate_terms()
+    h = robot._native()
+
+    # synthetic inputs, SURVEY 8d: rod b of the global batch gets its own period and phase
+    rng = np.random.default_rng(1235)
+    Pd = rng.uniform(0.5, 3.0, size=B * world)[rank * B:(rank + 1) * B]
+    phi = rng.uniform(0.0, 2 * np.pi, size=B * world)[rank * B:(rank + 1) * B]
+    i = np.arange(1, W + K + 1)[None, :, None]
+    k = np.arange(4)[None, None, :]
+    ctl = 6.0 + np.sin(2 * np.pi * i * robot.del_t / Pd[:, None, None] + phi[:, None, None] + k * (np.pi / 2))
+    ctl_t = torch.as_tensor(ctl, device=dev).to(tdt).contiguous()
+
+    states = h.new_state(B, tdt, n_slots=3)
+    h.init_straight(states[0])
+    G = torch.zeros((B, 6), dtype=tdt, device=dev)
+
+    # steps are issued one kr_step_batch launch each (ctl slice made contiguous outside the timed region)
+    ctl_steps = [ctl_t[:, t].contiguous() for t in range(W + K)]
+    st_steps = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(W + K)]
+
+    def step(t):
+        ic = t % 3
+        ip = (t + 2) % 3 if t else 0
+        inx = (t + 1) % 3
+        h.step(states[ip], states[ic], states[inx], G, ctl_steps[t], status=st_steps[t])
+
+    for t in range(W):
+        step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    ev0.record()
+    for t in range(W, W + K):
+        step(t)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        dist.barrier()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = ev0.elapsed_time(ev1) / K  # average duration of one step_kernel launch (HIP events on the launch stream)
+
+    n_bad = int(sum(int((s != 0).sum()) for s in st_steps))
+    final_tip = h.tip(states[(W + K) % 3]).cpu().numpy()
+
+    if rank == 0:
+        rod_steps = world * B * K
+        alg_bytes = B * (75 * N + 16) * esize  # single-step API, state in HBM each step
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "rod-steps/sec (N=100 segments, batch=1024)",
+            "value": round(rod_steps / elapsed, 1),
+            "unit": "rod-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"forward simulate, B={B} rods/GPU, N={N}, Euler shooting + BDF2, NN off, "
+                            f"setup_robot(None), per-rod sine tensions rng(1235)",
+                "rods_per_gpu": B, "N": N, "unconverged_rod_steps": n_bad,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel": "kr::step_kernel",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "dependent-chain latency bound at B=1024: 128 wavefronts on 1024 SIMDs, see DESIGN.md",
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            cb, tips = cpu_baseline(N, robot.del_t)
+            # tip parity of the GPU run against the oracle on the rods the CPU leg simulated (first steps)
+            import numpy as _np
+            Tc = tips[0].shape[0]
+            if Tc <= W + K:
+                st2 = h.new_state(len(tips), tdt, n_slots=3)
+                h.init_straight(st2[0])
+                G2 = torch.zeros((len(tips), 6), dtype=tdt, device=dev)
+                tip2 = torch.empty((len(tips), Tc, 3), dtype=tdt, device=dev)
+                c2 = torch.as_tensor(_np.stack([_cpu_ctl(b, Tc, robot.del_t) for b in range(len(tips))]), device=dev).to(tdt)
+                h.simulate(c2.contiguous(), st2, G2, ring=True, tip=tip2)
+                g = tip2.cpu().numpy()
+                errs = [float(_np.linalg.norm(g[b] - tips[b]) / _np.linalg.norm(tips[b])) for b in range(len(tips))]
+                out["tip_rel_l2_vs_oracle"] = max(errs)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _cpu_ctl(b, steps, del_t):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cosserat_oracle as orc
+    return orc.batch_sine_controls(max(b + 1, 16), steps, del_t, 1235)[b]
+
+
+if __name__ == "__main__":
+    main()

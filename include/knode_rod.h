@@ -201,23 +201,28 @@ int kr_next_segment_physics(kr_handle* h, int64_t S, int K, const void* Gs, cons
                             const void* tensions, const int32_t* idx, void* x, int in_pad, void* base,
                             int dtype, void* stream);
 
-/* Two-layer-or-deeper MLP forward over Q rows on the matrix cores (exact-f32
- * MFMA): out[Q][25] = MLP(x[Q][in_pad]); keeps the pre-activations the
- * backward pass needs in `ws` (kr_mlp_ws_bytes).  Weights are the caller's
- * device tensors (torch parameters), row-major like nn.Linear. */
+/* MLP forward over Q rows on the matrix cores (v_mfma_f32_32x32x2_f32: exact
+ * fp32, the reference's training precision): out[Q][32] (columns 0..24 valid,
+ * 25..31 zero) = MLP(x[Q][in_pad]); keeps pre-activations and activations of
+ * the hidden layers in `ws` (kr_mlp_ws_bytes) for the backward pass.  Weights
+ * are the caller's device tensors (torch parameters), row-major like nn.Linear:
+ * W[k][dims[k+1]][dims[k]], b[k][dims[k+1]]; acts[n_layers-1] must be NONE. */
 size_t kr_mlp_ws_bytes(int n_layers, const int32_t* dims, int64_t Q);
 int kr_mlp_forward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts,
                    const float* const* W, const float* const* b, const float* x, int in_pad, float* out,
                    void* ws, void* stream);
-/* dW[k], db[k] (+=0: overwritten) from dout[Q][25] */
+/* dW[k], db[k] (overwritten) from dout[Q][32] = d loss / d out and the `ws` of
+ * the matching forward call. */
 int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts,
                     const float* const* W, const float* x, int in_pad, const float* dout, const void* ws,
                     float* const* dW, float* const* db, void* stream);
 
-/* pred[row][25] = base + [ds*out[:19], out[19:]]; loss terms of
- * physics_train.py:252-259 against target[S][25][N] at columns idx[k]
- * (z rows against idx[k]-1); writes pred, the scalar loss (sum over s of the
- * four mean-squared terms, divided by `denom`) and dout[row][25] = dloss/dout. */
+/* pred[row][25] = base + [ds*out[:19], out[19:]] (row = s*K + k); four-term
+ * loss of physics_train.py:252-259 against target[S][25][N] at columns idx[k]
+ * (z rows against idx[k]-1, :259): for every s the sum of four nn.MSELoss
+ * (mean) terms - p rows, n/m/q/w rows, quaternion_to_euler(h rows), z rows -
+ * summed over s and divided by `denom`.  Writes pred, *loss and
+ * dout[row][32] = d loss / d out (columns 25..31 zero).  out is [rows][32]. */
 int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const float* out, const float* target,
                     const int32_t* idx, double denom, float* pred, float* loss, float* dout, void* stream);
 

@@ -1,0 +1,315 @@
+"""``CosseratRodTorch`` - the trainable twin of the rod model, backed by HIP.
+
+Drop-in for ``knode_cosserat/cosserat_ode_torch.py`` (reference lines 5-437):
+same constructor ``CosseratRodTorch(device, n_layers, nn_input_history=False)``,
+same attributes (``use_nn, y, z, tendon_tensions, residualArgs, nn_models,
+layers, c0, c1, c2, ds, ...``) and methods (``forward, ODE, ODE_parallel,
+getResidualEuler, getNextSegmentEuler, parallelGetNextSegmentEuler``).  The
+object stays picklable for ``torch.save({'robot': robot})``
+(physics_train.py:165,284).
+
+What runs where:
+  * rod physics ............ ``kr_ode_batch`` / ``kr_next_segment_physics`` (fp32, forward only:
+                             the physics has no trainable parameter)
+  * residual MLP ........... ``kr_mlp_forward`` / ``kr_mlp_backward`` - fp32 GEMMs on the matrix
+                             cores, wrapped in a ``torch.autograd.Function`` so the reference's
+                             training loop (torch loss -> ``backward()`` -> Adam) works unchanged
+  * parameters, optimizer .. plain torch tensors (``nn.ModuleList`` of ``nn.Linear`` / ``nn.ELU``)
+
+Gradients are produced for the MLP parameters only.  The reference additionally
+lets autograd flow into the *inputs* of ``ODE_parallel`` (cosserat_ode_torch.py:264-306);
+no caller uses those gradients and they are not provided here.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import krod_native as kn
+
+_ACT_CODE = {nn.Tanh: kn.ACT_TANH, nn.Softplus: kn.ACT_SOFTPLUS, nn.ReLU: kn.ACT_RELU, nn.ELU: kn.ACT_ELU}
+
+
+def mlp_structure(modules):
+    """[(linear, act_code), ...] from an ``nn.ModuleList`` of Linear / activation /
+    Dropout modules (the structures ``forward`` of the reference can express)."""
+    layers = []
+    for m in modules:
+        if isinstance(m, nn.Linear):
+            layers.append([m, kn.ACT_NONE])
+        elif type(m) in _ACT_CODE:
+            if not layers or layers[-1][1] != kn.ACT_NONE:
+                raise kn.KrError("unsupported MLP structure: activation without a preceding Linear layer")
+            if isinstance(m, nn.Softplus) and (m.beta != 1.0 or m.threshold != 20.0):
+                raise kn.KrError("only Softplus(beta=1, threshold=20) is supported")
+            if isinstance(m, nn.ELU) and m.alpha != 1.0:
+                raise kn.KrError("only ELU(alpha=1) is supported")
+            layers[-1][1] = _ACT_CODE[type(m)]
+        elif isinstance(m, nn.Dropout):
+            continue
+        else:
+            raise kn.KrError(f"unsupported module in the residual MLP: {m}")
+    return layers
+
+
+class _MlpFunction(torch.autograd.Function):
+    """out[Q, 32] = MLP(x[Q, in_pad]) on the matrix cores; backward fills the
+    parameter gradients with kr_mlp_backward."""
+
+    @staticmethod
+    def forward(ctx, handle, x, dims, acts, *params):
+        import ctypes as C
+        n = len(acts)
+        Ws = [p.contiguous() for p in params[0::2]]
+        bs = [p.contiguous() for p in params[1::2]]
+        Q = x.shape[0]
+        dims_c = (C.c_int32 * (n + 1))(*dims)
+        acts_c = (C.c_int32 * n)(*acts)
+        Wp = (C.c_void_p * n)(*[w.data_ptr() for w in Ws])
+        bp = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        ws_bytes = handle.lib.kr_mlp_ws_bytes(n, dims_c, max(Q, 1))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        out = torch.empty((Q, 32), dtype=torch.float32, device=x.device)
+        kn.check(handle.lib.kr_mlp_forward(handle._h, Q, n, dims_c, acts_c, Wp, bp, kn._ptr(x), x.shape[1],
+                                           kn._ptr(out), kn._ptr(ws), kn._stream()))
+        ctx.handle, ctx.dims, ctx.acts = handle, dims, acts
+        ctx.save_for_backward(x, ws, *Ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import ctypes as C
+        x, ws, *Ws = ctx.saved_tensors
+        handle, dims, acts = ctx.handle, ctx.dims, ctx.acts
+        n = len(acts)
+        Q = x.shape[0]
+        g = grad_out.contiguous().float()
+        dW = [torch.empty_like(w) for w in Ws]
+        db = [torch.empty(w.shape[0], dtype=torch.float32, device=x.device) for w in Ws]
+        dims_c = (C.c_int32 * (n + 1))(*dims)
+        acts_c = (C.c_int32 * n)(*acts)
+        Wp = (C.c_void_p * n)(*[w.data_ptr() for w in Ws])
+        dWp = (C.c_void_p * n)(*[w.data_ptr() for w in dW])
+        dbp = (C.c_void_p * n)(*[b.data_ptr() for b in db])
+        kn.check(handle.lib.kr_mlp_backward(handle._h, Q, n, dims_c, acts_c, Wp, kn._ptr(x), x.shape[1], kn._ptr(g),
+                                            kn._ptr(ws), dWp, dbp, kn._stream()))
+        grads = []
+        for a, b in zip(dW, db):
+            grads += [a, b]
+        return (None, None, None, None, *grads)
+
+
+class CosseratRodTorch:
+    def __init__(self, device, n_layers, nn_input_history=False):
+        self.device = device
+        self.use_nn = True
+        self.nn_input_history = nn_input_history
+        self.verbose = False
+        self.y = None
+        self.z = None
+        # independent parameters, reference defaults (cosserat_ode_torch.py:14-45)
+        self.L = 0.4
+        self.N = 10
+        self.E = 109e9
+        self.r = 0.0012
+        self.rho = 8000.
+        dev = self.device
+        self.vstar = torch.tensor([0., 0., 1.], device=dev)
+        self.g = torch.tensor([0, 0, -9.81], device=dev)
+        self.Bse = torch.zeros((3, 3), device=dev)
+        self.Bbt = torch.diag(torch.tensor([3e-2, 3e-2, 3e-2], device=dev))
+        self.C = torch.tensor([1e-4, 1e-4, 1e-4], device=dev)
+        self.del_t = 0.005
+        self.F_tip = torch.zeros(3, device=dev)
+        self.M_tip = torch.zeros(3, device=dev)
+        self.T0 = 5
+        self.n_tendons = 4
+        self.tendon_tensions = None
+        self.tendon_offset = 0.02
+        th = np.pi / self.n_tendons
+        self.tendon_dirs = torch.tensor(
+            [[np.cos(th + k * np.pi / 2), np.sin(th + k * np.pi / 2), 0.0] for k in range(4)],
+            dtype=torch.float32).to(dev)
+        self.p0 = torch.zeros(3, device=dev)
+        self.h0 = torch.tensor([1., 0., 0., 0.], device=dev)
+        self.q0 = torch.zeros(3, device=dev)
+        self.w0 = torch.zeros(3, device=dev)
+        self._handle = None
+        self.compute_intermediate_terms()
+        self.residualArgs = {"yh": None, "zh": None, "tendon_forces": None}
+
+        # residual MLP, cosserat_ode_torch.py:60-88: Linear -> ELU -> Linear, weights |N(0.01, 0.01)|,
+        # biases N(0, 0.01)
+        width = int(n_layers)
+        self.layers = [nn.Linear(53 if self.nn_input_history else 28, width), nn.ELU(), nn.Linear(width, 25)]
+        for layer in self.layers:
+            if isinstance(layer, nn.Linear):
+                self.non_negative_normal_init(layer, mean=0.01, std=0.01)
+                nn.init.normal_(layer.bias, mean=0.0, std=0.01)
+        self.nn_models = nn.ModuleList(self.layers).to(self.device)
+
+    def non_negative_normal_init(self, m, mean, std):
+        """cosserat_ode_torch.py:90-105"""
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            assert mean >= 0, "Mean must be non-negative"
+            with torch.no_grad():
+                m.weight.data.normal_(mean, std).abs_()
+
+    # ------------------------------------------------------------------
+    # parameters
+    # ------------------------------------------------------------------
+    def _np(self, a):
+        return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
+    def _params(self) -> kn.KrParams:
+        f = self._np
+        return kn.params_from_dict(dict(
+            L=float(self.L), N=int(self.N), nn_input_history=int(bool(self.nn_input_history)), E=float(self.E),
+            r=float(self.r), rho=float(self.rho), vstar=f(self.vstar), g=f(self.g), Bse=f(self.Bse), Bbt=f(self.Bbt),
+            C=f(self.C), del_t=float(self.del_t), F_tip=f(self.F_tip), M_tip=f(self.M_tip),
+            tendon_dirs=f(self.tendon_dirs), p0=f(self.p0), h0=f(self.h0), q0=f(self.q0), w0=f(self.w0)))
+
+    def compute_intermediate_terms(self):
+        """cosserat_ode_torch.py:108-129; the dependent terms come from kr_derive."""
+        d = kn.derive(self._params())
+        dev = self.device
+        m3 = lambda a: torch.tensor(np.array(a, dtype=np.float64).reshape(3, 3), dtype=torch.float32, device=dev)
+        self.A, self.G, self.ds = d.A, d.G, d.ds
+        self.J, self.Kse, self.Kbt = m3(d.J), m3(d.Kse), m3(d.Kbt)
+        self.c0, self.c1, self.c2 = d.c0, d.c1, d.c2
+        self.Kse_plus_c0_Bse_inv = m3(d.Kse_plus_c0_Bse_inv)
+        self.Kbt_plus_c0_Bbt_inv = m3(d.Kbt_plus_c0_Bbt_inv)
+        self.Kse_vstar = torch.tensor(list(d.Kse_vstar), dtype=torch.float32, device=dev)
+        self.rhoA = d.rhoA
+        self.rhoAg = torch.tensor(list(d.rhoAg), dtype=torch.float32, device=dev)
+        self.rhoJ = m3(d.rhoJ)
+
+    def _device_index(self) -> int:
+        d = torch.device(self.device)
+        if d.type != "cuda":
+            raise kn.KrError(f"CosseratRodTorch computes on the MI355X only; device={self.device!r} has no kernels")
+        return d.index if d.index is not None else torch.cuda.current_device()
+
+    def _native(self) -> kn.Handle:
+        p = self._params()
+        if self._handle is None:
+            self._handle = kn.Handle(p, self._device_index())
+        else:
+            self._handle.set_params(p)
+        return self._handle
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_handle"] = None
+        return st
+
+    # ------------------------------------------------------------------
+    # MLP
+    # ------------------------------------------------------------------
+    def _mlp(self, x_padded):
+        """out[Q, 25] for padded input rows x[Q, in_pad] (HIP GEMMs, differentiable w.r.t. the parameters)."""
+        struct = mlp_structure(self.nn_models)
+        dims = [struct[0][0].in_features] + [l.out_features for l, _ in struct]
+        acts = [a for _, a in struct]
+        params = []
+        for l, _ in struct:
+            if l.bias is None:
+                raise kn.KrError("Linear layers of the residual MLP need a bias")
+            params += [l.weight, l.bias]
+        out = _MlpFunction.apply(self._native(), x_padded, tuple(dims), tuple(acts), *params)
+        return out[:, :25]
+
+    def forward(self, x):
+        """cosserat_ode_torch.py:131-134; accepts [in] or [Q, in]."""
+        single = x.dim() == 1
+        xx = x.reshape(1, -1) if single else x
+        in_dim = xx.shape[1]
+        pad = (in_dim + 31) // 32 * 32
+        xp = torch.zeros((xx.shape[0], pad), dtype=torch.float32, device=xx.device)
+        xp[:, :in_dim] = xx.float()
+        out = self._mlp(xp)
+        return out[0] if single else out
+
+    # ------------------------------------------------------------------
+    # physics
+    # ------------------------------------------------------------------
+    def ODE_parallel(self, ys, yhs, zhs, tendon_forcess):
+        """Batched arc-length derivative, cosserat_ode_torch.py:217-322:
+        [Q,19],[Q,19],[Q,6],[Q,3] -> (dys[Q,19], z[Q,6])."""
+        h = self._native()
+        c = lambda t: t.detach().float().contiguous()
+        y_, yh_, zh_, tf_ = c(ys), c(yhs), c(zhs), c(tendon_forcess)
+        dys, z = h.ode_batch(y_, yh_, zh_, tf_, use_nn=False)
+        if self.use_nn:
+            parts = [y_, yh_, z, zh_, tf_] if self.nn_input_history else [y_, z, tf_]
+            x = torch.cat(parts, dim=1)
+            out = self.forward(x)
+            dys = dys + out[:, :19]
+            z = z + out[:, 19:]
+        return dys, z
+
+    def ODE(self, y, yh, zh, tendon_forces):
+        """Single grid point, cosserat_ode_torch.py:137-214."""
+        dys, z = self.ODE_parallel(y.reshape(1, 19), yh.reshape(1, 19), zh.reshape(1, 6), tendon_forces.reshape(1, 3))
+        return dys[0], z[0]
+
+    def _next_segment(self, Gs, yhs, zhs, tensions, idx):
+        """pred[S, K, 25] for key columns idx (1-based columns of the output, see
+        cosserat_ode_torch.py:412)."""
+        h = self._native()
+        S, K = Gs.shape[0], len(idx)
+        dev = Gs.device
+        c = lambda t: t.detach().float().contiguous()
+        idx_t = torch.as_tensor(np.asarray(idx, dtype=np.int32), device=dev)
+        in_dim = 53 if self.nn_input_history else 28
+        pad = (in_dim + 31) // 32 * 32
+        x = torch.empty((S * K, pad), dtype=torch.float32, device=dev)
+        base = torch.empty((S * K, 25), dtype=torch.float32, device=dev)
+        kn.check(h.lib.kr_next_segment_physics(h._h, S, K, kn._ptr(c(Gs)), kn._ptr(c(yhs)), kn._ptr(c(zhs)),
+                                               kn._ptr(c(tensions)), kn._ptr(idx_t), kn._ptr(x), pad, kn._ptr(base),
+                                               kn.KR_F32, kn._stream()))
+        if not self.use_nn:
+            return base.reshape(S, K, 25)
+        out = self._mlp(x)
+        pred = base + torch.cat([self.ds * out[:, :19], out[:, 19:]], dim=1)
+        return pred.reshape(S, K, 25)
+
+    def parallelGetNextSegmentEuler(self, Gs, segment_idxs, args):
+        """cosserat_ode_torch.py:401-437: Gs[S,25,N], key columns -> [S,25,K]."""
+        pred = self._next_segment(Gs, args["yh"], args["zh"], args["tendon_tensions"], np.asarray(segment_idxs))
+        return pred.transpose(1, 2)
+
+    def getNextSegmentEuler(self, G):
+        """cosserat_ode_torch.py:370-399: teacher-forced one-step predictor for every segment,
+        G[25,N] -> full_rod[25,N] (column 0 is the guess itself)."""
+        N = int(self.N)
+        yh, zh = self.residualArgs["yh"], self.residualArgs["zh"]
+        pred = self._next_segment(G.reshape(1, 25, N), yh.reshape(1, 19, N), zh.reshape(1, 6, N),
+                                  self.tendon_tensions.reshape(1, 4), np.arange(1, N))
+        first = G.detach().float()[:, :1]
+        return torch.cat([first, pred[0].transpose(0, 1)], dim=1)
+
+    def getResidualEuler(self, G):
+        """cosserat_ode_torch.py:325-367: one full shooting sweep from the guessed base wrench
+        G[6] -> (sum of squared tip residuals, full_rod[25,N]).  Forward only."""
+        h = self._native()
+        N = int(self.N)
+        dev = G.device
+        c = lambda t: t.detach().float().contiguous()
+        hist = h.pack(c(self.residualArgs["yh"]).reshape(1, 19, N), c(self.residualArgs["zh"]).reshape(1, 6, N))
+        nxt = h.new_state(1, torch.float32)
+        tens = c(self.tendon_tensions).reshape(1, 4)
+        use_nn = bool(self.use_nn)
+        if use_nn:
+            struct = mlp_structure(self.nn_models)
+            h.set_mlp([l.weight.detach().cpu().numpy() for l, _ in struct],
+                      [l.bias.detach().cpu().numpy() for l, _ in struct], [a for _, a in struct])
+        r = h.residual(c(G).reshape(1, 6), None, hist, nxt, tens, use_nn=use_nn, hist_is_explicit=True)
+        y_new, z_new = h.unpack(nxt)
+        # column layout of the reference's full_rod: column 0 = [y0; z[:,0] of the caller], column j+1 = [y_{j+1}; z_j]
+        z_in = c(self.z) if self.z is not None else torch.zeros((6, N), device=dev)
+        full = torch.cat([torch.cat([y_new[0, :, :1], z_in[:, :1]], dim=0),
+                          torch.cat([y_new[0, :, 1:], z_new[0, :, : N - 1]], dim=0)], dim=1)
+        self.y = y_new[0]
+        return torch.sum(r[0] ** 2), full

@@ -28,7 +28,7 @@ __device__ __forceinline__ void tile_out(T* __restrict__ g, const T* l, int64_t 
   for (int64_t i = tid; i < lim; i += ODE_ROWS) g[base + i] = l[i];
 }
 
-template <typename T, bool NN, bool NNHIST>
+template <typename T, bool DIAG, bool NN, bool NNHIST>
 __global__ __launch_bounds__(ODE_ROWS) void ode_batch_kernel(const RodConst<T> P, const MlpDev<T> M, int64_t Q,
                                                              const T* __restrict__ y, const T* __restrict__ yh,
                                                              const T* __restrict__ zh, const T* __restrict__ tf,
@@ -56,11 +56,12 @@ __global__ __launch_bounds__(ODE_ROWS) void ode_batch_kernel(const RodConst<T> P
     hst.wh = {syh[tid * 19 + 16], syh[tid * 19 + 17], syh[tid * 19 + 18]};
     hst.vh = {szh[tid * 6 + 0], szh[tid * 6 + 1], szh[tid * 6 + 2]};
     hst.uh = {szh[tid * 6 + 3], szh[tid * 6 + 4], szh[tid * 6 + 5]};
+    hist_derive(P, hst);
     const V3<T> tfv{stf[tid * 3 + 0], stf[tid * 3 + 1], stf[tid * 3 + 2]};
     const V3<T> fconst{P.rhoAg[0] + tfv.x, P.rhoAg[1] + tfv.y, P.rhoAg[2] + tfv.z};
     RodState<T> k;
     V3<T> v, u;
-    ode_eval<T>(P, ys_in, hst, fconst, k, v, u);
+    ode_eval<T, DIAG>(P, ys_in, hst, fconst, k, v, u);
     T out[25];
     {
       T kr_[19];
@@ -171,8 +172,14 @@ int launch_ode_batch(kr_handle* h, int64_t Q, const T* y, const T* yh, const T* 
   }
   const bool hist = h->params.nn_input_history != 0;
 #define KR_LAUNCH(NNv, Hv)                                                                                  \
-  hipLaunchKernelGGL((ode_batch_kernel<T, NNv, Hv>), dim3(grid), dim3(ODE_ROWS), 0, s, P, M, Q, y, yh, zh, tf, \
-                     dys, z, act)
+  do {                                                                                                      \
+    if (P.diag)                                                                                             \
+      hipLaunchKernelGGL((ode_batch_kernel<T, true, NNv, Hv>), dim3(grid), dim3(ODE_ROWS), 0, s, P, M, Q, y, yh, zh, \
+                         tf, dys, z, act);                                                                  \
+    else                                                                                                    \
+      hipLaunchKernelGGL((ode_batch_kernel<T, false, NNv, Hv>), dim3(grid), dim3(ODE_ROWS), 0, s, P, M, Q, y, yh, zh, \
+                         tf, dys, z, act);                                                                  \
+  } while (0)
   if (!use_nn) KR_LAUNCH(false, false);
   else if (!hist) KR_LAUNCH(true, false);
   else KR_LAUNCH(true, true);

@@ -91,6 +91,13 @@ __device__ __forceinline__ void load_hist_vec(const T* src, T (&hv)[HS]) {
   }
 }
 
+// History record layout (LDS or global scratch), HS values per grid point:
+//   0..2 q_h  3..5 w_h  6..8 v_h  9..11 u_h  12..14 av  15..17 au
+//   HS == HS_PHYS (20): 18..19 padding
+//   HS == HS_NNH  (32): 18..30 history of p h n m (MLP input when nn_input_history), 31 padding
+constexpr int HS_PHYS = 20;
+constexpr int HS_NNH = 32;
+
 template <typename T, int HS>
 __device__ __forceinline__ RodHist<T> hist_from(const T (&hv)[HS]) {
   RodHist<T> h;
@@ -98,7 +105,53 @@ __device__ __forceinline__ RodHist<T> hist_from(const T (&hv)[HS]) {
   h.wh = {hv[3], hv[4], hv[5]};
   h.vh = {hv[6], hv[7], hv[8]};
   h.uh = {hv[9], hv[10], hv[11]};
+  h.av = {hv[12], hv[13], hv[14]};
+  h.au = {hv[15], hv[16], hv[17]};
   return h;
+}
+
+// history record of one grid point from the packed states of the two previous
+// time levels (knode.py:74-75): raw = hc1*cur + hc2*prev, then av / au.
+template <typename T, int HS>
+__device__ __forceinline__ void build_hist_point(const RodConst<T>& P, T hc1, T hc2, const T* __restrict__ c,
+                                                 const T* __restrict__ p, T* dst) {
+  constexpr int NR = (HS == HS_NNH) ? 25 : 12;
+  constexpr int NRP = (NR + Vec16<T>::n - 1) / Vec16<T>::n * Vec16<T>::n;  // stays inside the 28-slot record
+  T cv[NRP], pv[NRP];
+  load_hist_vec<T, NRP>(c, cv);
+  load_hist_vec<T, NRP>(p, pv);
+  T raw[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) raw[k] = hc1 * cv[k] + hc2 * pv[k];
+  T hv[HS];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) hv[k] = raw[k];
+  RodHist<T> h;
+  h.qh = {raw[0], raw[1], raw[2]};
+  h.wh = {raw[3], raw[4], raw[5]};
+  h.vh = {raw[6], raw[7], raw[8]};
+  h.uh = {raw[9], raw[10], raw[11]};
+  hist_derive(P, h);
+  hv[12] = h.av.x; hv[13] = h.av.y; hv[14] = h.av.z;
+  hv[15] = h.au.x; hv[16] = h.au.y; hv[17] = h.au.z;
+  if constexpr (HS == HS_NNH) {
+#pragma unroll
+    for (int k = 0; k < 13; ++k) hv[18 + k] = raw[12 + k];
+    hv[31] = T(0);
+  } else {
+    hv[18] = T(0);
+    hv[19] = T(0);
+  }
+  using V = typename Vec16<T>::type;
+  constexpr int n = Vec16<T>::n;
+  V* d = reinterpret_cast<V*>(dst);
+#pragma unroll
+  for (int k = 0; k < HS / n; ++k) {
+    V v;
+#pragma unroll
+    for (int e = 0; e < n; ++e) v[e] = hv[k * n + e];
+    d[k] = v;
+  }
 }
 
 // 6x6 solve, Gaussian elimination with partial pivoting on static indices.
@@ -145,10 +198,10 @@ __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB,
 #pragma unroll
   for (int i = 0; i < 19; ++i) bufA[(o + i) * stride] = yr[i];
   o += 19;
-  if constexpr (HS == 25) {
-    // yh in reference row order p h n m q w  <- history slots 12..24, 0..5
+  if constexpr (HS == HS_NNH) {
+    // yh in reference row order p h n m q w  <- record entries 18..30, 0..5
 #pragma unroll
-    for (int i = 0; i < 13; ++i) bufA[(o + i) * stride] = hv[12 + i];
+    for (int i = 0; i < 13; ++i) bufA[(o + i) * stride] = hv[18 + i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) bufA[(o + 13 + i) * stride] = hv[i];
     o += 19;
@@ -156,7 +209,7 @@ __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB,
   bufA[(o + 0) * stride] = v.x; bufA[(o + 1) * stride] = v.y; bufA[(o + 2) * stride] = v.z;
   bufA[(o + 3) * stride] = u.x; bufA[(o + 4) * stride] = u.y; bufA[(o + 5) * stride] = u.z;
   o += 6;
-  if constexpr (HS == 25) {
+  if constexpr (HS == HS_NNH) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) bufA[(o + i) * stride] = hv[6 + i];
     o += 6;
@@ -188,15 +241,15 @@ struct SweepCtx {
 };
 
 // one ODE evaluation incl. the optional network correction
-template <typename T, bool NN, int HS>
+template <typename T, bool DIAG, bool NN, int HS>
 __device__ __forceinline__ void eval_point(const RodConst<T>& P, const MlpDev<T>& M, const SweepCtx<T, HS>& C,
                                            const RodState<T>& y, const T (&hv)[HS], RodState<T>& k, V3<T>& v,
                                            V3<T>& u) {
-  ode_eval<T>(P, y, hist_from<T, HS>(hv), C.fconst, k, v, u);
+  ode_eval<T, DIAG>(P, y, hist_from<T, HS>(hv), C.fconst, k, v, u);
   if constexpr (NN) nn_correct<T, HS>(M, C.bufA, C.bufB, C.astride, y, hv, C.tf, k, v, u);
 }
 
-template <typename T, int SCHEME, bool HIST_LDS, bool NN, int HS>
+template <typename T, bool DIAG, int SCHEME, bool HIST_LDS, bool NN, int HS>
 __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const StepArgs<T> A, const MlpDev<T> M) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -213,17 +266,13 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
   SweepCtx<T, HS> C;
   // ---- BDF2 history terms (knode.py:74-75) --------------------------------
   if constexpr (HIST_LDS) {
-    for (int r = 0; r < RPW; ++r) {
+    for (int pt = lane; pt < RPW * N; pt += WAVE) {
+      const int r = pt / N;
+      const int j = pt - r * N;
       int64_t rr = (int64_t)blockIdx.x * RPW + r;
       if (rr >= A.B) rr = A.B - 1;
-      const T* c = A.cur + rr * rod_elems;
-      const T* p = A.prev + rr * rod_elems;
-      T* dst = smem + (size_t)r * N * HS;
-      for (int idx = lane; idx < N * HS; idx += WAVE) {
-        const int j = idx / HS;
-        const int k = idx - j * HS;
-        dst[idx] = A.hc1 * c[j * KR_SLOTS + k] + A.hc2 * p[j * KR_SLOTS + k];
-      }
+      const size_t off = rr * rod_elems + (size_t)j * KR_SLOTS;
+      build_hist_point<T, HS>(P, A.hc1, A.hc2, A.cur + off, A.prev + off, smem + (size_t)pt * HS);
     }
     __syncthreads();
     C.hbase = smem + (size_t)rl * N * HS;
@@ -302,7 +351,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
     for (int j = 0; j < N - 1; ++j) {
       RodState<T> k1;
       V3<T> v, u;
-      eval_point<T, NN, HS>(P, M, C, y, hv, k1, v, u);
+      eval_point<T, DIAG, NN, HS>(P, M, C, y, hv, k1, v, u);
       if (st) {
         T rec[KR_SLOTS];
         record_from(y, v, u, rec);
@@ -321,11 +370,11 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
         RodState<T> k2, k3, k4;
         V3<T> v2, u2;
         RodState<T> ya = state_axpy(y, P.ds * T(0.5), k1);
-        eval_point<T, NN, HS>(P, M, C, ya, hm, k2, v2, u2);
+        eval_point<T, DIAG, NN, HS>(P, M, C, ya, hm, k2, v2, u2);
         ya = state_axpy(y, P.ds * T(0.5), k2);
-        eval_point<T, NN, HS>(P, M, C, ya, hm, k3, v2, u2);
+        eval_point<T, DIAG, NN, HS>(P, M, C, ya, hm, k3, v2, u2);
         ya = state_axpy(y, P.ds, k3);
-        eval_point<T, NN, HS>(P, M, C, ya, hn, k4, v2, u2);
+        eval_point<T, DIAG, NN, HS>(P, M, C, ya, hn, k4, v2, u2);
         RodState<T> ksum = state_axpy(k1, T(2), k2);
         ksum = state_axpy(ksum, T(2), k3);
         ksum = state_axpy(ksum, T(1), k4);
@@ -414,20 +463,17 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
 
 // history into global scratch when it does not fit in LDS
 template <typename T, int HS>
-__global__ void hist_kernel(int N, T hc1, T hc2, int64_t B, const T* __restrict__ cur, const T* __restrict__ prev,
-                            T* __restrict__ hist) {
-  const int64_t total = B * (int64_t)N * HS;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pt = i / HS;
-    const int k = (int)(i - pt * HS);
-    hist[i] = hc1 * cur[pt * KR_SLOTS + k] + hc2 * prev[pt * KR_SLOTS + k];
-  }
+__global__ void hist_kernel(const RodConst<T> P, T hc1, T hc2, int64_t B, const T* __restrict__ cur,
+                            const T* __restrict__ prev, T* __restrict__ hist) {
+  const int64_t total = B * (int64_t)P.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    build_hist_point<T, HS>(P, hc1, hc2, cur + i * KR_SLOTS, prev + i * KR_SLOTS, hist + i * HS);
 }
 
-template <typename T, int SCHEME, bool HIST_LDS, bool NN, int HS>
+template <typename T, bool DIAG, int SCHEME, bool HIST_LDS, bool NN, int HS>
 static int launch_step_inst(const RodConst<T>& P, const MlpDev<T>& M, const StepArgs<T>& a, size_t smem,
                             hipStream_t s) {
-  auto kern = step_kernel<T, SCHEME, HIST_LDS, NN, HS>;
+  auto kern = step_kernel<T, DIAG, SCHEME, HIST_LDS, NN, HS>;
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -470,25 +516,29 @@ static int launch_step_mem(kr_handle* h, StepArgs<T> a, hipStream_t s) {
     if (!hist_in_lds) {
       a.hist_ws = reinterpret_cast<T*>(w);
       w += hist_bytes;
-      hipLaunchKernelGGL((hist_kernel<T, HS>), dim3(1024), dim3(256), 0, s, N, a.hc1, a.hc2, a.B, a.cur, a.prev, a.hist_ws);
+      hipLaunchKernelGGL((hist_kernel<T, HS>), dim3(1024), dim3(256), 0, s, P, a.hc1, a.hc2, a.B, a.cur, a.prev, a.hist_ws);
       KR_HIP(hipGetLastError());
     }
     if (NN && !act_in_lds) a.act_ws = reinterpret_cast<T*>(w);
   }
   const size_t smem = (hist_in_lds ? hist_lds : 0) + (act_in_lds ? act_lds : 0);
-  if (hist_in_lds) return launch_step_inst<T, SCHEME, true, NN, HS>(P, M, a, smem, s);
-  return launch_step_inst<T, SCHEME, false, NN, HS>(P, M, a, smem, s);
+  if (P.diag) {
+    if (hist_in_lds) return launch_step_inst<T, true, SCHEME, true, NN, HS>(P, M, a, smem, s);
+    return launch_step_inst<T, true, SCHEME, false, NN, HS>(P, M, a, smem, s);
+  }
+  if (hist_in_lds) return launch_step_inst<T, false, SCHEME, true, NN, HS>(P, M, a, smem, s);
+  return launch_step_inst<T, false, SCHEME, false, NN, HS>(P, M, a, smem, s);
 }
 
 template <typename T, int SCHEME>
 static int launch_step_nn(kr_handle* h, int use_nn, const StepArgs<T>& a, hipStream_t s) {
-  if (!use_nn) return launch_step_mem<T, SCHEME, false, 12>(h, a, s);
+  if (!use_nn) return launch_step_mem<T, SCHEME, false, HS_PHYS>(h, a, s);
   if (mlpdev<T>(h).n_layers <= 0) {
     set_error("use_nn requested but no MLP was set (kr_set_mlp)");
     return KR_E_STATE;
   }
-  if (h->params.nn_input_history) return launch_step_mem<T, SCHEME, true, 25>(h, a, s);
-  return launch_step_mem<T, SCHEME, true, 12>(h, a, s);
+  if (h->params.nn_input_history) return launch_step_mem<T, SCHEME, true, HS_NNH>(h, a, s);
+  return launch_step_mem<T, SCHEME, true, HS_PHYS>(h, a, s);
 }
 
 template <typename T>

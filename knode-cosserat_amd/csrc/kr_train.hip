@@ -1,26 +1,566 @@
-// kr_train.hip - KNODE one-step-ahead training path (placeholder until the kernels land in this round).
+// kr_train.hip - KNODE one-step-ahead training path.
+//
+//   kr_next_segment_physics  the physics half of CosseratRodTorch.parallelGetNextSegmentEuler
+//                            (reference cosserat_ode_torch.py:401-437; with idx = 1..N-1 it is
+//                            getNextSegmentEuler, :370-399): gathers the key columns of the
+//                            teacher-forced next state, evaluates the rod derivative there and
+//                            emits (a) the MLP input rows and (b) the prediction without the MLP.
+//   kr_mlp_forward/backward  the residual MLP (cosserat_ode_torch.py:60-62,131-134) over Q rows
+//                            as dense GEMMs on the matrix cores: v_mfma_f32_32x32x2_f32, i.e.
+//                            exact fp32 like the reference's training arithmetic.
+//   kr_loss_fwd_bwd          prediction assembly + the four-term loss of physics_train.py:252-259
+//                            (incl. Utils/transformations.quaternion_to_euler) + its gradient with
+//                            respect to the MLP output.
+//
+// The physics has no trainable parameter and the reference feeds ground-truth columns to every
+// segment ("y and z are not updated here", cosserat_ode_torch.py:391), so d loss / d theta flows only
+// through the MLP output: training = elementwise physics (forward only) + MLP forward/backward.
 #include "kr_internal.hpp"
+
+namespace kr {
+
+// ---------------------------------------------------------------------------
+// T1: physics rows
+// ---------------------------------------------------------------------------
+template <typename T, bool DIAG>
+__global__ void next_segment_physics_kernel(const RodConst<T> P, int64_t S, int K, int hist, const T* __restrict__ Gs,
+                                            const T* __restrict__ yh, const T* __restrict__ zh,
+                                            const T* __restrict__ tens, const int32_t* __restrict__ idx,
+                                            T* __restrict__ x, int in_pad, T* __restrict__ base) {
+  const int N = P.N;
+  const int64_t rows = S * K;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = row / K;
+    const int k = (int)(row - s * K);
+    const int j = idx[k] - 1;  // cosserat_ode_torch.py:412 gathers column segment_idx-1
+    T yr[19], yhr[19], zhr[6];
+#pragma unroll
+    for (int r = 0; r < 19; ++r) yr[r] = Gs[(s * 25 + r) * N + j];
+#pragma unroll
+    for (int r = 0; r < 19; ++r) yhr[r] = yh[(s * 19 + r) * N + j];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) zhr[r] = zh[(s * 6 + r) * N + j];
+    V3<T> tf{T(0), T(0), T(0)};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const T tt = tens[s * 4 + t];
+      tf.x += tt * P.tdirs[t * 3 + 0];
+      tf.y += tt * P.tdirs[t * 3 + 1];
+      tf.z += tt * P.tdirs[t * 3 + 2];
+    }
+    const V3<T> fconst{P.rhoAg[0] + tf.x, P.rhoAg[1] + tf.y, P.rhoAg[2] + tf.z};
+    RodState<T> y = rows_to_state(yr);
+    RodHist<T> hst;
+    hst.qh = {yhr[13], yhr[14], yhr[15]};
+    hst.wh = {yhr[16], yhr[17], yhr[18]};
+    hst.vh = {zhr[0], zhr[1], zhr[2]};
+    hst.uh = {zhr[3], zhr[4], zhr[5]};
+    hist_derive(P, hst);
+    RodState<T> ks;
+    V3<T> v, u;
+    ode_eval<T, DIAG>(P, y, hst, fconst, ks, v, u);
+    T ksr[19];
+    state_to_rows(ks, ksr);
+    T* b = base + row * 25;
+#pragma unroll
+    for (int r = 0; r < 19; ++r) b[r] = yr[r] + P.ds * ksr[r];
+    b[19] = v.x; b[20] = v.y; b[21] = v.z; b[22] = u.x; b[23] = u.y; b[24] = u.z;
+    // MLP input, cosserat_ode_torch.py:310-313
+    T* xr = x + row * in_pad;
+    int o = 0;
+#pragma unroll
+    for (int r = 0; r < 19; ++r) xr[o + r] = yr[r];
+    o += 19;
+    if (hist) {
+#pragma unroll
+      for (int r = 0; r < 19; ++r) xr[o + r] = yhr[r];
+      o += 19;
+    }
+    xr[o + 0] = v.x; xr[o + 1] = v.y; xr[o + 2] = v.z; xr[o + 3] = u.x; xr[o + 4] = u.y; xr[o + 5] = u.z;
+    o += 6;
+    if (hist) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) xr[o + r] = zhr[r];
+      o += 6;
+    }
+    xr[o + 0] = tf.x; xr[o + 1] = tf.y; xr[o + 2] = tf.z;
+    o += 3;
+    for (; o < in_pad; ++o) xr[o] = T(0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// T2/T3: fp32 GEMM on the matrix cores
+// ---------------------------------------------------------------------------
+// C[m][n] = sum_k A(m,k) B(k,n) with A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+// (arbitrary strides cover every transpose the MLP needs).  Workgroup = 4 waves,
+// tile 128 x 32, K in steps of 32 staged through LDS; each wave owns a 32 x 32
+// tile and issues 16 v_mfma_f32_32x32x2_f32 per K step (A: lane l holds
+// A[row l&31][k = l>>5], B: lane l holds B[k = l>>5][col l&31]; the two k lanes
+// of an instruction take k = t and k = t+16 of the staged block so that every
+// LDS read below is conflict free).
+enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_MUL_ACTGRAD = 2, EPI_ATOMIC = 3 };
+constexpr int GM = 128, GN = 32, GK = 32;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  int M, N, K;
+  const float* A; int64_t sam, sak;
+  const float* B; int64_t sbk, sbn;
+  float* C; int64_t ldc;        // C[m*ldc + n]
+  const float* bias;            // EPI_BIAS_ACT: bias[n] (n < n_valid)
+  float* C2;                    // EPI_BIAS_ACT: activations act(C) (same ldc); EPI_MUL_ACTGRAD: pre-activations
+  int act;
+  int n_valid;                  // columns >= n_valid are written as zero (padding)
+  int k_chunk;                  // split-K: K range per blockIdx.z
+};
+
+template <int EPI, bool A_KCONTIG, bool B_NCONTIG>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs g) {
+  __shared__ float As[GM][GK + 1];
+  __shared__ float Bs[GK][GN + 1];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int m0 = blockIdx.x * GM;
+  const int n0 = blockIdx.y * GN;
+  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kend = min(g.K, kbeg + g.k_chunk);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    // stage A tile (128 x 32): 16 elements per thread
+#pragma unroll
+    for (int e = 0; e < (GM * GK) / 256; ++e) {
+      const int lin = e * 256 + tid;
+      int mm, kk;
+      if (A_KCONTIG) { mm = lin / GK; kk = lin % GK; }
+      else { kk = lin / GM; mm = lin % GM; }
+      const int m = m0 + mm, k = k0 + kk;
+      As[mm][kk] = (m < g.M && k < kend) ? g.A[m * g.sam + k * g.sak] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < (GK * GN) / 256; ++e) {
+      const int lin = e * 256 + tid;
+      int kk, nn;
+      if (B_NCONTIG) { kk = lin / GN; nn = lin % GN; }
+      else { nn = lin / GK; kk = lin % GK; }
+      const int k = k0 + kk, n = n0 + nn;
+      Bs[kk][nn] = (k < kend && n < g.n_valid) ? g.B[k * g.sbk + n * g.sbn] : 0.f;
+    }
+    __syncthreads();
+    const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float a = As[wave * 32 + r][kh * 16 + t];
+      const float b = Bs[kh * 16 + t][r];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int n = n0 + (lane & 31);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = m0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    if (m >= g.M || n >= g.N) continue;
+    float v = acc[reg];
+    const int64_t o = (int64_t)m * g.ldc + n;
+    if (EPI == EPI_STORE) {
+      g.C[o] = n < g.n_valid ? v : 0.f;
+    } else if (EPI == EPI_BIAS_ACT) {
+      if (n < g.n_valid) {
+        v += g.bias[n];
+        g.C[o] = v;
+        if (g.C2) g.C2[o] = activate<float>(g.act, v);
+      } else {
+        g.C[o] = 0.f;
+        if (g.C2) g.C2[o] = 0.f;
+      }
+    } else if (EPI == EPI_MUL_ACTGRAD) {
+      g.C[o] = n < g.n_valid ? v * activate_grad<float>(g.act, g.C2[o]) : 0.f;
+    } else {
+      if (n < g.n_valid) atomicAdd(&g.C[o], v);
+    }
+  }
+}
+
+template <int EPI>
+static int launch_gemm(const GemmArgs& g, bool a_kcontig, bool b_ncontig, int splits, hipStream_t s) {
+  dim3 grid((g.M + GM - 1) / GM, (g.N + GN - 1) / GN, splits);
+  if (a_kcontig && b_ncontig) hipLaunchKernelGGL((gemm_f32_mfma<EPI, true, true>), grid, dim3(256), 0, s, g);
+  else if (a_kcontig) hipLaunchKernelGGL((gemm_f32_mfma<EPI, true, false>), grid, dim3(256), 0, s, g);
+  else if (b_ncontig) hipLaunchKernelGGL((gemm_f32_mfma<EPI, false, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_f32_mfma<EPI, false, false>), grid, dim3(256), 0, s, g);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+// column sums of d[Q][ld] -> out[n] (bias gradients); out pre-zeroed
+__global__ void colsum_kernel(int64_t Q, int n, int ld, const float* __restrict__ d, float* __restrict__ out) {
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int64_t chunk = (Q + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * chunk;
+  const int64_t r1 = r0 + chunk < Q ? r0 + chunk : Q;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += d[r * ld + c];
+  atomicAdd(&out[c], s);
+}
+
+static inline int pad32(int v) { return (v + 31) / 32 * 32; }
+
+// workspace layout of one forward pass: for every layer k < n_layers-1 the
+// pre-activations Z_k[Q][pad32(dims[k+1])] followed by the activations A_k of the
+// same shape; then two scratch buffers of the widest hidden shape for the
+// backward sweep.
+struct MlpWs {
+  float* Z[KR_MAX_LAYERS];
+  float* Aact[KR_MAX_LAYERS];
+  float* d0;
+  float* d1;
+  size_t bytes;
+};
+static MlpWs carve_ws(void* ws, int n_layers, const int32_t* dims, int64_t Q) {
+  MlpWs w{};
+  unsigned char* p = static_cast<unsigned char*>(ws);
+  size_t off = 0;
+  int maxh = 32;
+  for (int k = 0; k + 1 < n_layers; ++k) {
+    const size_t sz = ((size_t)Q * pad32(dims[k + 1]) * sizeof(float) + 255) & ~size_t(255);
+    w.Z[k] = reinterpret_cast<float*>(p + off); off += sz;
+    w.Aact[k] = reinterpret_cast<float*>(p + off); off += sz;
+    if (pad32(dims[k + 1]) > maxh) maxh = pad32(dims[k + 1]);
+  }
+  const size_t sz = ((size_t)Q * maxh * sizeof(float) + 255) & ~size_t(255);
+  w.d0 = reinterpret_cast<float*>(p + off); off += sz;
+  w.d1 = reinterpret_cast<float*>(p + off); off += sz;
+  w.bytes = off;
+  return w;
+}
+
+// ---------------------------------------------------------------------------
+// T4: prediction + four-term loss + gradient w.r.t. the MLP output
+// ---------------------------------------------------------------------------
+// quaternion_to_euler of Utils/transformations.py:3-31 and its Jacobian-transpose product
+__device__ __forceinline__ void q2e(const float q[4], float e[3]) {
+  const float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+  e[0] = atan2f(2.f * (w * y + x * z), 1.f - 2.f * (y * y + z * z));
+  e[1] = asinf(fminf(fmaxf(2.f * (w * z - x * y), -1.f), 1.f));
+  e[2] = atan2f(2.f * (w * x + y * z), 1.f - 2.f * (x * x + z * z));
+}
+__device__ __forceinline__ void q2e_vjp(const float q[4], const float ge[3], float gq[4]) {
+  const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float inv = 1.f / nrm;
+  const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+  float gn[4] = {0.f, 0.f, 0.f, 0.f};  // gradient w.r.t. the normalised quaternion (w, x, y, z)
+  {  // roll = atan2(a, b)
+    const float a = 2.f * (w * y + x * z), b = 1.f - 2.f * (y * y + z * z);
+    const float den = a * a + b * b;
+    const float ga = ge[0] * b / den, gb = -ge[0] * a / den;
+    gn[0] += ga * 2.f * y; gn[1] += ga * 2.f * z; gn[2] += ga * 2.f * w - gb * 4.f * y; gn[3] += ga * 2.f * x - gb * 4.f * z;
+  }
+  {  // pitch = asin(clamp(s))
+    const float s = 2.f * (w * z - x * y);
+    if (s >= -1.f && s <= 1.f) {
+      const float gs = ge[1] / sqrtf(1.f - s * s);
+      gn[0] += gs * 2.f * z; gn[1] -= gs * 2.f * y; gn[2] -= gs * 2.f * x; gn[3] += gs * 2.f * w;
+    }
+  }
+  {  // yaw = atan2(c, d)
+    const float c = 2.f * (w * x + y * z), d = 1.f - 2.f * (x * x + z * z);
+    const float den = c * c + d * d;
+    const float gc = ge[2] * d / den, gd = -ge[2] * c / den;
+    gn[0] += gc * 2.f * x; gn[1] += gc * 2.f * w - gd * 4.f * x; gn[2] += gc * 2.f * z; gn[3] += gc * 2.f * y - gd * 4.f * z;
+  }
+  const float dot = gn[0] * w + gn[1] * x + gn[2] * y + gn[3] * z;
+  gq[0] = (gn[0] - w * dot) * inv;
+  gq[1] = (gn[1] - x * dot) * inv;
+  gq[2] = (gn[2] - y * dot) * inv;
+  gq[3] = (gn[3] - z * dot) * inv;
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, int K, const float* __restrict__ base,
+                                                   const float* __restrict__ out, int ld_out,
+                                                   const float* __restrict__ target, const int32_t* __restrict__ idx,
+                                                   float inv_denom, float* __restrict__ pred,
+                                                   float* __restrict__ loss, float* __restrict__ dout, int ld_dout) {
+  const int64_t rows = S * K;
+  float part = 0.f;
+  // weights of the four nn.MSELoss(mean) terms: each is a mean over (rows of the block) x K
+  const float w_p = inv_denom / (3.f * K), w_r = inv_denom / (12.f * K), w_e = inv_denom / (3.f * K),
+              w_z = inv_denom / (6.f * K);
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = row / K;
+    const int k = (int)(row - s * K);
+    const int jc = idx[k];
+    float p[25], g[25];
+#pragma unroll
+    for (int r = 0; r < 19; ++r) p[r] = base[row * 25 + r] + ds * out[row * ld_out + r];
+#pragma unroll
+    for (int r = 19; r < 25; ++r) p[r] = base[row * 25 + r] + out[row * ld_out + r];
+#pragma unroll
+    for (int r = 0; r < 25; ++r) pred[row * 25 + r] = p[r];
+    const float* tg = target + s * 25 * (int64_t)N;
+    // positions, physics_train.py:252-253
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float d = p[r] - tg[r * N + jc];
+      part += w_p * d * d;
+      g[r] = 2.f * w_p * d;
+    }
+    // n m q w, :254-255
+#pragma unroll
+    for (int r = 7; r < 19; ++r) {
+      const float d = p[r] - tg[r * N + jc];
+      part += w_r * d * d;
+      g[r] = 2.f * w_r * d;
+    }
+    // Euler angles of the quaternion, :256-257
+    {
+      float qp[4] = {p[3], p[4], p[5], p[6]};
+      float qt[4] = {tg[3 * N + jc], tg[4 * N + jc], tg[5 * N + jc], tg[6 * N + jc]};
+      float ep[3], et[3], ge[3], gq[4];
+      q2e(qp, ep);
+      q2e(qt, et);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = ep[c] - et[c];
+        part += w_e * d * d;
+        ge[c] = 2.f * w_e * d;
+      }
+      q2e_vjp(qp, ge, gq);
+      g[3] = gq[0]; g[4] = gq[1]; g[5] = gq[2]; g[6] = gq[3];
+    }
+    // z rows against the column before the key point, :258-259
+#pragma unroll
+    for (int r = 19; r < 25; ++r) {
+      const float d = p[r] - tg[r * N + (jc - 1)];
+      part += w_z * d * d;
+      g[r] = 2.f * w_z * d;
+    }
+    // chain through pred = base + [ds*out[:19], out[19:]]
+#pragma unroll
+    for (int r = 0; r < 19; ++r) dout[row * ld_dout + r] = ds * g[r];
+#pragma unroll
+    for (int r = 19; r < 25; ++r) dout[row * ld_dout + r] = g[r];
+    for (int r = 25; r < ld_dout; ++r) dout[row * ld_dout + r] = 0.f;
+  }
+  // block reduction of the loss
+  __shared__ float red[256];
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss, red[0]);
+}
+
+}  // namespace kr
+
 using namespace kr;
+
+#define KR_CHECK_H(h)            \
+  if (!(h)) {                    \
+    set_error("null handle");    \
+    return KR_E_ARG;             \
+  }
+#define KR_CHECK_PTR(p)                        \
+  if (!(p)) {                                  \
+    set_error("null pointer argument: " #p);   \
+    return KR_E_ARG;                           \
+  }
+
+static int check_mlp_shape(int n_layers, const int32_t* dims) {
+  if (n_layers < 1 || n_layers > KR_MAX_LAYERS || !dims) {
+    set_error("n_layers out of range");
+    return KR_E_ARG;
+  }
+  for (int k = 0; k <= n_layers; ++k)
+    if (dims[k] <= 0) {
+      set_error("bad layer width");
+      return KR_E_ARG;
+    }
+  if (dims[n_layers] != 25) {
+    set_error("the residual MLP must end in 25 outputs (cosserat_ode_torch.py:62)");
+    return KR_E_ARG;
+  }
+  return KR_OK;
+}
+
 extern "C" {
-int kr_next_segment_physics(kr_handle*, int64_t, int, const void*, const void*, const void*, const void*,
-                            const int32_t*, void*, int, void*, int, void*) {
-  set_error("kr_next_segment_physics: not implemented yet");
-  return KR_E_UNSUPPORTED;
+
+int kr_next_segment_physics(kr_handle* h, int64_t S, int K, const void* Gs, const void* yh, const void* zh,
+                            const void* tensions, const int32_t* idx, void* x, int in_pad, void* base, int dtype,
+                            void* stream) {
+  KR_CHECK_H(h);
+  if (dtype != KR_F32 && dtype != KR_F64) { set_error("bad dtype"); return KR_E_ARG; }
+  if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
+  if (S == 0 || K == 0) return KR_OK;
+  KR_CHECK_PTR(Gs); KR_CHECK_PTR(yh); KR_CHECK_PTR(zh); KR_CHECK_PTR(tensions); KR_CHECK_PTR(idx);
+  KR_CHECK_PTR(x); KR_CHECK_PTR(base);
+  const int hist = h->params.nn_input_history ? 1 : 0;
+  const int need = hist ? 53 : 28;
+  if (in_pad < need) { set_error("in_pad smaller than the MLP input width"); return KR_E_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t rows = S * K;
+  int grid = (int)((rows + 255) / 256);
+  if (grid > 4096) grid = 4096;
+#define KR_NS(T, D)                                                                                          \
+  hipLaunchKernelGGL((next_segment_physics_kernel<T, D>), dim3(grid), dim3(256), 0, s, consts<T>(h), S, K, hist, \
+                     (const T*)Gs, (const T*)yh, (const T*)zh, (const T*)tensions, idx, (T*)x, in_pad, (T*)base)
+  if (dtype == KR_F32) {
+    if (h->cf.diag) KR_NS(float, true); else KR_NS(float, false);
+  } else {
+    if (h->cd.diag) KR_NS(double, true); else KR_NS(double, false);
+  }
+#undef KR_NS
+  KR_HIP(hipGetLastError());
+  return KR_OK;
 }
-size_t kr_mlp_ws_bytes(int, const int32_t*, int64_t) { return 0; }
-int kr_mlp_forward(kr_handle*, int64_t, int, const int32_t*, const int32_t*, const float* const*, const float* const*,
-                   const float*, int, float*, void*, void*) {
-  set_error("kr_mlp_forward: not implemented yet");
-  return KR_E_UNSUPPORTED;
+
+size_t kr_mlp_ws_bytes(int n_layers, const int32_t* dims, int64_t Q) {
+  if (n_layers < 1 || n_layers > KR_MAX_LAYERS || !dims || Q <= 0) return 0;
+  return carve_ws(nullptr, n_layers, dims, Q).bytes;
 }
-int kr_mlp_backward(kr_handle*, int64_t, int, const int32_t*, const int32_t*, const float* const*, const float*, int,
-                    const float*, const void*, float* const*, float* const*, void*) {
-  set_error("kr_mlp_backward: not implemented yet");
-  return KR_E_UNSUPPORTED;
+
+int kr_mlp_forward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts,
+                   const float* const* W, const float* const* b, const float* x, int in_pad, float* out, void* ws,
+                   void* stream) {
+  KR_CHECK_H(h);
+  int rc = check_mlp_shape(n_layers, dims);
+  if (rc) return rc;
+  if (Q < 0) { set_error("Q < 0"); return KR_E_ARG; }
+  if (Q == 0) return KR_OK;
+  KR_CHECK_PTR(acts); KR_CHECK_PTR(W); KR_CHECK_PTR(b); KR_CHECK_PTR(x); KR_CHECK_PTR(out);
+  if (n_layers > 1) KR_CHECK_PTR(ws);
+  if (in_pad < dims[0]) { set_error("in_pad < dims[0]"); return KR_E_ARG; }
+  if (acts[n_layers - 1] != KR_ACT_NONE) {
+    set_error("an activation after the last layer is not supported by the training path");
+    return KR_E_UNSUPPORTED;
+  }
+  if (Q > (int64_t)1 << 30) { set_error("Q too large"); return KR_E_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MlpWs w = carve_ws(ws, n_layers, dims, Q);
+  const float* in = x;
+  int64_t ld_in = in_pad;
+  for (int k = 0; k < n_layers; ++k) {
+    const bool last = (k == n_layers - 1);
+    GemmArgs g{};
+    g.M = (int)Q; g.K = dims[k];
+    g.A = in; g.sam = ld_in; g.sak = 1;
+    g.B = W[k]; g.sbk = 1; g.sbn = dims[k];  // B(k,n) = W[n][k]  (nn.Linear layout)
+    g.bias = b[k];
+    g.act = acts[k];
+    g.n_valid = dims[k + 1];
+    g.k_chunk = g.K;
+    if (last) {
+      g.N = 32; g.C = out; g.ldc = 32; g.C2 = nullptr;
+    } else {
+      g.N = pad32(dims[k + 1]); g.C = w.Z[k]; g.C2 = w.Aact[k]; g.ldc = g.N;
+    }
+    rc = launch_gemm<EPI_BIAS_ACT>(g, true, false, 1, s);
+    if (rc) return rc;
+    if (!last) { in = w.Aact[k]; ld_in = g.N; }
+  }
+  return KR_OK;
 }
-int kr_loss_fwd_bwd(kr_handle*, int64_t, int, const float*, const float*, const float*, const int32_t*, double, float*,
-                    float*, float*, void*) {
-  set_error("kr_loss_fwd_bwd: not implemented yet");
-  return KR_E_UNSUPPORTED;
+
+int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts,
+                    const float* const* W, const float* x, int in_pad, const float* dout, const void* ws,
+                    float* const* dW, float* const* db, void* stream) {
+  KR_CHECK_H(h);
+  int rc = check_mlp_shape(n_layers, dims);
+  if (rc) return rc;
+  if (Q < 0) { set_error("Q < 0"); return KR_E_ARG; }
+  KR_CHECK_PTR(acts); KR_CHECK_PTR(W); KR_CHECK_PTR(dW); KR_CHECK_PTR(db);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int k = 0; k < n_layers; ++k) {
+    KR_CHECK_PTR(dW[k]); KR_CHECK_PTR(db[k]);
+    KR_HIP(hipMemsetAsync(dW[k], 0, sizeof(float) * dims[k] * dims[k + 1], s));
+    KR_HIP(hipMemsetAsync(db[k], 0, sizeof(float) * dims[k + 1], s));
+  }
+  if (Q == 0) return KR_OK;
+  KR_CHECK_PTR(x); KR_CHECK_PTR(dout);
+  if (n_layers > 1) KR_CHECK_PTR(ws);
+  MlpWs w = carve_ws(const_cast<void*>(ws), n_layers, dims, Q);
+  const float* dz = dout;  // d loss / d (pre-activation of layer k); the last layer has no activation
+  int64_t ld_dz = 32;
+  if (acts[n_layers - 1] != KR_ACT_NONE) {
+    set_error("an activation after the last layer is not supported by the training path");
+    return KR_E_UNSUPPORTED;
+  }
+  for (int k = n_layers - 1; k >= 0; --k) {
+    const float* a_prev = k == 0 ? x : w.Aact[k - 1];
+    const int64_t ld_prev = k == 0 ? in_pad : pad32(dims[k]);
+    // dW[k][o][i] = sum_r dz[r][o] * a_prev[r][i]   (contraction over the Q rows: split-K + atomics)
+    {
+      GemmArgs g{};
+      g.M = dims[k + 1]; g.N = dims[k]; g.K = (int)Q;
+      g.A = dz; g.sam = 1; g.sak = ld_dz;
+      g.B = a_prev; g.sbk = ld_prev; g.sbn = 1;
+      g.C = dW[k]; g.ldc = dims[k];
+      g.n_valid = dims[k];
+      int splits = (int)((Q + 2047) / 2048);
+      if (splits > 1024) splits = 1024;
+      g.k_chunk = (int)(((Q + splits - 1) / splits + GK - 1) / GK * GK);
+      splits = (int)((Q + g.k_chunk - 1) / g.k_chunk);
+      rc = launch_gemm<EPI_ATOMIC>(g, false, true, splits, s);
+      if (rc) return rc;
+    }
+    {
+      int gx = (int)((Q + 4095) / 4096);
+      if (gx > 512) gx = 512;
+      dim3 grid(gx, (dims[k + 1] + 63) / 64);
+      hipLaunchKernelGGL(colsum_kernel, grid, dim3(64), 0, s, Q, dims[k + 1], (int)ld_dz, dz, db[k]);
+      KR_HIP(hipGetLastError());
+    }
+    if (k > 0) {
+      // dz_{k-1}[r][i] = (sum_o dz[r][o] W[k][o][i]) * act'(Z_{k-1}[r][i])
+      GemmArgs g{};
+      g.M = (int)Q; g.N = pad32(dims[k]); g.K = dims[k + 1];
+      g.A = dz; g.sam = ld_dz; g.sak = 1;
+      g.B = W[k]; g.sbk = dims[k]; g.sbn = 1;
+      float* dst = (dz == w.d0) ? w.d1 : w.d0;
+      g.C = dst; g.ldc = g.N;
+      g.C2 = w.Z[k - 1];
+      g.act = acts[k - 1];
+      g.n_valid = dims[k];
+      g.k_chunk = g.K;
+      // B is read with n contiguous only inside the valid columns; guard handles n >= N
+      GemmArgs g2 = g;
+      g2.N = g.N;
+      rc = launch_gemm<EPI_MUL_ACTGRAD>(g2, true, true, 1, s);
+      if (rc) return rc;
+      dz = dst;
+      ld_dz = g.N;
+    }
+  }
+  return KR_OK;
 }
+
+int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const float* out, const float* target,
+                    const int32_t* idx, double denom, float* pred, float* loss, float* dout, void* stream) {
+  KR_CHECK_H(h);
+  if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
+  KR_CHECK_PTR(loss);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KR_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+  if (S == 0 || K == 0) return KR_OK;
+  KR_CHECK_PTR(base); KR_CHECK_PTR(out); KR_CHECK_PTR(target); KR_CHECK_PTR(idx); KR_CHECK_PTR(pred); KR_CHECK_PTR(dout);
+  if (!(denom > 0)) { set_error("denom must be positive"); return KR_E_ARG; }
+  const int64_t rows = S * K;
+  int grid = (int)((rows + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, s, h->params.N, (float)h->derived.ds, S, K, base, out, 32,
+                     target, idx, (float)(1.0 / denom), pred, loss, dout, 32);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
 }
+
+}  // extern "C"

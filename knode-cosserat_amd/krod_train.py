@@ -1,0 +1,173 @@
+"""Fused KNODE training step and its data-parallel form.
+
+Restates the epoch body of ``physics_train.py`` (slow loop :209-304, ``--fast``
+loop :306-408) on top of the HIP kernels:
+
+    for every trajectory and every window step t (29 of them):
+        pred = one-step-ahead predictor at the key points      (a12 / a13)
+        loss += MSE(p) + MSE(n,m,q,w) + MSE(euler(h)) + MSE(z vs column key-1)
+    loss /= 29;  backward;  Adam(lr=1e-2);  ReduceLROnPlateau;  clamp weights >= 0
+
+Two facts of the reference make this cheap on a GPU:
+  * every (trajectory, t, key point) row is independent - one batched launch;
+  * the physics part of the predictor does not depend on the MLP parameters,
+    so the MLP input rows ``x`` and the parameter-free part of the prediction
+    ``base`` are computed once per data set, not once per epoch.
+
+Per epoch the device work is: MLP forward (MFMA GEMMs) -> fused prediction +
+loss + d loss/d out -> MLP backward (MFMA GEMMs) -> one all-reduce of the flat
+gradient buffer (RCCL over xGMI, data parallel only) -> Adam + clamp.
+
+Both reference loops reduce to this with different key points: the slow loop
+evaluates all segments but scores columns [2, 6, 9] (``batch_idx`` at :220 is
+just ``stp_idx``), the fast loop evaluates and scores [3, 5, 7, 9].
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+import krod_native as kn
+from cosserat_ode_torch import mlp_structure
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous, balanced split of n items: rank r gets [lo, hi)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatBucket:
+    """One flat fp32 buffer holding every parameter gradient plus one trailing
+    slot for the loss, so a training step needs exactly one all-reduce."""
+
+    def __init__(self, shapes, device):
+        self.shapes = [tuple(s) for s in shapes]
+        self.sizes = [int(np.prod(s)) for s in self.shapes]
+        self.flat = torch.zeros(sum(self.sizes) + 1, dtype=torch.float32, device=device)
+        self.views, off = [], 0
+        for s, n in zip(self.shapes, self.sizes):
+            self.views.append(self.flat[off:off + n].view(s))
+            off += n
+        self.loss = self.flat[off:off + 1]
+
+    def all_reduce(self, group=None):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+
+class KnodeTrainer:
+    """One-step-ahead KNODE training on a fixed set of trajectories.
+
+    trajs    float32 [M, T, 25, N]  reference trajectories (``simulate(...)[:, :25]``)
+    controls float32 [M, T, 4]
+    Each rank passes its own shard of the M trajectories (see ``shard_range``);
+    gradients and the loss are summed over ranks, which reproduces the
+    single-process result of the reference exactly (its loss is a sum over
+    trajectories, physics_train.py:215-267).
+    """
+
+    def __init__(self, robot, trajs, controls, key_pt_idx, lr=1e-2, weight_decay=0.0, clamp_weights=True,
+                 patience=80, factor=0.5, group=None):
+        self.robot = robot
+        self.group = group
+        self.clamp_weights = clamp_weights
+        h = robot._native()
+        self.h = h
+        dev = trajs.device
+        trajs = trajs.float().contiguous()
+        controls = controls.float().contiguous()
+        M, T, _, N = trajs.shape
+        assert N == int(robot.N)
+        self.M, self.T, self.N = M, T, N
+        self.steps = T - 1  # batch_len - 1 = 29 in the reference
+        self.idx = np.asarray(key_pt_idx, dtype=np.int32)
+        self.K = len(self.idx)
+        self.idx_t = torch.as_tensor(self.idx, device=dev)
+        S = M * (T - 1)
+        self.S = S
+        # physics_train.py:318-333: states t = 0..T-2, previous state (first one repeated), next state as guess
+        ys, zs = trajs[:, : T - 1, :19], trajs[:, : T - 1, 19:]
+        y_prev = torch.cat([ys[:, :1], ys[:, :-1]], dim=1)
+        z_prev = torch.cat([zs[:, :1], zs[:, :-1]], dim=1)
+        yh = (robot.c1 * ys + robot.c2 * y_prev).reshape(S, 19, N).contiguous()
+        zh = (robot.c1 * zs + robot.c2 * z_prev).reshape(S, 6, N).contiguous()
+        self.target = trajs[:, 1:T].reshape(S, 25, N).contiguous()
+        tens = controls[:, : T - 1].reshape(S, 4).contiguous()
+        in_dim = 53 if robot.nn_input_history else 28
+        self.in_pad = (in_dim + 31) // 32 * 32
+        Q = S * self.K
+        self.Q = Q
+        self.x = torch.empty((Q, self.in_pad), dtype=torch.float32, device=dev)
+        self.base = torch.empty((Q, 25), dtype=torch.float32, device=dev)
+        if Q:
+            kn.check(h.lib.kr_next_segment_physics(h._h, S, self.K, kn._ptr(self.target), kn._ptr(yh), kn._ptr(zh),
+                                                   kn._ptr(tens), kn._ptr(self.idx_t), kn._ptr(self.x), self.in_pad,
+                                                   kn._ptr(self.base), kn.KR_F32, kn._stream()))
+        # MLP description
+        self.struct = mlp_structure(robot.nn_models)
+        self.n = len(self.struct)
+        dims = [self.struct[0][0].in_features] + [l.out_features for l, _ in self.struct]
+        self.dims_c = (C.c_int32 * (self.n + 1))(*dims)
+        self.acts_c = (C.c_int32 * self.n)(*[a for _, a in self.struct])
+        self.params = []
+        for l, _ in self.struct:
+            self.params += [l.weight, l.bias]
+        self.bucket = FlatBucket([p.shape for p in self.params], dev)
+        for p, v in zip(self.params, self.bucket.views):
+            p.grad = v  # Adam reads the all-reduced gradients straight from the flat buffer
+        ws_bytes = h.lib.kr_mlp_ws_bytes(self.n, self.dims_c, max(Q, 1))
+        self.ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        self.out = torch.zeros((max(Q, 1), 32), dtype=torch.float32, device=dev)
+        self.dout = torch.zeros((max(Q, 1), 32), dtype=torch.float32, device=dev)
+        self.pred = torch.zeros((max(Q, 1), 25), dtype=torch.float32, device=dev)
+        self.optimizer = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", patience=patience,
+                                                                    factor=factor)
+
+    def _ptr_arrays(self):
+        n = self.n
+        Wp = (C.c_void_p * n)(*[self.params[2 * k].data_ptr() for k in range(n)])
+        bp = (C.c_void_p * n)(*[self.params[2 * k + 1].data_ptr() for k in range(n)])
+        dWp = (C.c_void_p * n)(*[self.bucket.views[2 * k].data_ptr() for k in range(n)])
+        dbp = (C.c_void_p * n)(*[self.bucket.views[2 * k + 1].data_ptr() for k in range(n)])
+        return Wp, bp, dWp, dbp
+
+    def loss_and_grads(self):
+        """Forward + loss + backward + gradient all-reduce.  Leaves the summed
+        gradients in ``p.grad`` and returns the (device) loss scalar."""
+        h, s = self.h, kn._stream()
+        Wp, bp, dWp, dbp = self._ptr_arrays()
+        Q = self.Q
+        kn.check(h.lib.kr_mlp_forward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, bp, kn._ptr(self.x), self.in_pad,
+                                      kn._ptr(self.out), kn._ptr(self.ws), s))
+        kn.check(h.lib.kr_loss_fwd_bwd(h._h, self.S, self.K, kn._ptr(self.base), kn._ptr(self.out),
+                                       kn._ptr(self.target), kn._ptr(self.idx_t), float(self.steps),
+                                       kn._ptr(self.pred), kn._ptr(self.bucket.loss), kn._ptr(self.dout), s))
+        kn.check(h.lib.kr_mlp_backward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, kn._ptr(self.x), self.in_pad,
+                                       kn._ptr(self.dout), kn._ptr(self.ws), dWp, dbp, s))
+        self.bucket.all_reduce(self.group)
+        return self.bucket.loss
+
+    def step(self, sync_loss=True):
+        """One epoch of physics_train.py: returns the loss (float if sync_loss)."""
+        loss = self.loss_and_grads()
+        self.optimizer.step()
+        if sync_loss:
+            val = float(loss.item())
+            self.scheduler.step(val)
+        else:
+            val = loss
+        if self.clamp_weights:  # physics_train.py:299-304 - hits every weight matrix
+            with torch.no_grad():
+                for k in range(self.n):
+                    self.params[2 * k].clamp_(min=0)
+        return val
+
+    def predictions(self):
+        """[S, 25, K] predictions of the last forward pass (reference layout of grow_trajs)."""
+        return self.pred[: self.Q].reshape(self.S, self.K, 25).transpose(1, 2)
