@@ -27,6 +27,21 @@ sys.path.insert(0, os.path.join(ROOT, "knode-cosserat_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
+def pmc_traffic(B, N, dtype):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_hbm.json,
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if no profile matches this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == f"B={B} N={N} {dtype} Euler":
+            best = d.get("hbm_bytes_per_launch_corrected")
+    return best
+
+
 def cpu_baseline(N, del_t_unused, sample_steps=24):
     """Times the oracle (NumPy port of cosserat_ode.py + knode.simulate with
     scipy fsolve - the reference's own execution model) on the host: one rod
@@ -177,7 +192,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": pmc_traffic(B, N, args.dtype),
                 "kernel": "kr::step_kernel",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
