@@ -6,8 +6,9 @@ per GPU B=1024 rods, N=100 grid points, explicit-Euler shooting sweep inside an
 implicit BDF2 time step, fp64 (the reference's NumPy path is fp64), NN off,
 setup_robot(mod=None) parameters, per-rod sinusoidal tendon tensions
 (SURVEY 8d cfg3 inputs, default_rng(1235)).  One bench "step" = one time step of
-the whole batch = one launch of the shooting kernel (kr_step_batch through
-kr_simulate_batch, state resident in HBM: 3 packed-state slots used as a ring).
+the whole batch; the K timed steps are one kr_simulate_batch call (state resident in
+HBM as a 3-slot ring of packed states; at this batch size the library runs them
+as ONE persistent launch in which every wavefront keeps its rod).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nodes-per-rod N] [--dtype f64|f32]
 
@@ -27,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "knode-cosserat_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
-def pmc_traffic(B, N, dtype):
+def pmc_traffic(B, N, dtype, path, steps):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_hbm.json,
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if no profile matches this workload."""
     import glob
@@ -37,7 +38,7 @@ def pmc_traffic(B, N, dtype):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") == f"B={B} N={N} {dtype} Euler":
+        if d.get("workload") == f"B={B} N={N} {dtype} Euler" and d.get("sim_path", 0) == path and d.get("steps_per_launch", 1) == steps:
             best = d.get("hbm_bytes_per_launch_corrected")
     return best
 
@@ -121,27 +122,24 @@ def main():
     rng = np.random.default_rng(1235)
     Pd = rng.uniform(0.5, 3.0, size=B * world)[rank * B:(rank + 1) * B]
     phi = rng.uniform(0.0, 2 * np.pi, size=B * world)[rank * B:(rank + 1) * B]
-    i = np.arange(1, W + K + 1)[None, :, None]
     k = np.arange(4)[None, None, :]
-    ctl = 6.0 + np.sin(2 * np.pi * i * robot.del_t / Pd[:, None, None] + phi[:, None, None] + k * (np.pi / 2))
-    ctl_t = torch.as_tensor(ctl, device=dev).to(tdt).contiguous()
 
+    # state lives in HBM as a 3-slot ring of packed states; kr_simulate_batch advances it W (+K) steps.
+    # W is rounded up to a multiple of 3 so that the timed call starts at ring slot 0 again, with the
+    # state before it in slot 2 (handed over as state_prev_init: the run continues exactly).
+    W = (W + 2) // 3 * 3
+    i = np.arange(1, W + K + 1)[None, :, None]
+    ctl = 6.0 + np.sin(2 * np.pi * i * robot.del_t / Pd[:, None, None] + phi[:, None, None] + k * (np.pi / 2))
+    ctl_w = torch.as_tensor(ctl[:, :W], device=dev).to(tdt).contiguous()
+    ctl_k = torch.as_tensor(ctl[:, W:], device=dev).to(tdt).contiguous()
     states = h.new_state(B, tdt, n_slots=3)
     h.init_straight(states[0])
     G = torch.zeros((B, 6), dtype=tdt, device=dev)
+    status = torch.zeros((B, K), dtype=torch.int32, device=dev)
+    tip = torch.empty((B, K, 3), dtype=tdt, device=dev)
 
-    # steps are issued one kr_step_batch launch each (ctl slice made contiguous outside the timed region)
-    ctl_steps = [ctl_t[:, t].contiguous() for t in range(W + K)]
-    st_steps = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(W + K)]
-
-    def step(t):
-        ic = t % 3
-        ip = (t + 2) % 3 if t else 0
-        inx = (t + 1) % 3
-        h.step(states[ip], states[ic], states[inx], G, ctl_steps[t], status=st_steps[t])
-
-    for t in range(W):
-        step(t)
+    if W:
+        h.simulate(ctl_w, states, G, ring=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -149,8 +147,7 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     ev0.record()
-    for t in range(W, W + K):
-        step(t)
+    h.simulate(ctl_k, states, G, ring=True, tip=tip, status=status, prev_init=states[2] if W else None)
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
@@ -159,14 +156,20 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kernel_ms = ev0.elapsed_time(ev1) / K  # average duration of one step_kernel launch (HIP events on the launch stream)
+    kernel_ms = ev0.elapsed_time(ev1)  # duration of the K-step region on the launch stream (HIP events)
 
-    n_bad = int(sum(int((s != 0).sum()) for s in st_steps))
-    final_tip = h.tip(states[(W + K) % 3]).cpu().numpy()
+    n_bad = int((status != 0).sum())
 
     if rank == 0:
         rod_steps = world * B * K
-        alg_bytes = B * (75 * N + 16) * esize  # single-step API, state in HBM each step
+        path = h.get_option("last_sim_path")  # 2: the K steps ran as one persistent launch
+        persistent = path == 2
+        # SURVEY 8d algorithmic bytes per rod-step: state written every step (25 N + 4) s in the persistent
+        # form (history never leaves the CU); (75 N + 16) s when every step is its own launch
+        per_rod_step = (25 * N + 4) * esize if persistent else (75 * N + 16) * esize
+        launches = 1 if persistent else K
+        alg_bytes = B * per_rod_step * (K if persistent else 1)
+        kernel_ms = kernel_ms / launches
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "rod-steps/sec (N=100 segments, batch=1024)",
@@ -192,11 +195,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic(B, N, args.dtype),
-                "kernel": "kr::step_kernel",
+                "traffic": pmc_traffic(B, N, args.dtype, path, K if persistent else 1),
+                "kernel": ("kr::ms_sim_kernel (persistent, all K steps in one launch)", "kr::ms_step_kernel",
+                           "kr::step_kernel")[2 - path] if path in (0, 1, 2) else "?",
                 "kernel_ms": round(kernel_ms, 4),
+                "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "dependent-chain latency bound at B=1024: 128 wavefronts on 1024 SIMDs, see DESIGN.md",
+                "note": "fp64 VALU issue bound, not HBM bound: one rod per wavefront on each of the 1024 SIMDs, "
+                        "4 Newton sweeps x 25 grid points x ~240 fp64 instructions per step (DESIGN.md section 4)",
             },
         }
         if world == 1 and not args.no_cpu:
@@ -211,6 +217,7 @@ def main():
                 tip2 = torch.empty((len(tips), Tc, 3), dtype=tdt, device=dev)
                 c2 = torch.as_tensor(_np.stack([_cpu_ctl(b, Tc, robot.del_t) for b in range(len(tips))]), device=dev).to(tdt)
                 h.simulate(c2.contiguous(), st2, G2, ring=True, tip=tip2)
+                torch.cuda.synchronize()
                 g = tip2.cpu().numpy()
                 errs = [float(_np.linalg.norm(g[b] - tips[b]) / _np.linalg.norm(tips[b])) for b in range(len(tips))]
                 out["tip_rel_l2_vs_oracle"] = max(errs)

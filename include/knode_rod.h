@@ -113,6 +113,22 @@ int kr_apply_preset(kr_params* inout, const char* mod);
 
 int kr_create(const kr_params* p, int device, kr_handle** out);
 int kr_destroy(kr_handle* h);
+/* Solver options (integers):
+ *   "ms_mode"        -1 auto (default) / 0 off / 1 forced: multiple-shooting form of the time-step
+ *                    kernel (one rod per wavefront, 4 sub-intervals) for small batches
+ *   "ms_batch_limit" auto mode uses it when B <= limit (default 2048)
+ *   "persistent"     1 (default) / 0: kr_simulate_batch runs all steps in one launch when the
+ *                    multiple-shooting kernel applies
+ *   "predictor"      0..2: highest order of the time extrapolation kr_simulate_batch uses for
+ *                    the initial guess of each step (default 2; 0 = the reference's warm start) */
+int kr_set_option(kr_handle* h, const char* name, int value);
+/* reads an option back; additionally "last_sim_path": what the last kr_simulate_batch did -
+ * 0 one single-shooting launch per step, 1 one multiple-shooting launch per step, 2 one
+ * persistent launch for all steps */
+int kr_get_option(kr_handle* h, const char* name, int* value);
+/* Diagnostic builds only (-DKR_MS_STAMPS): device buffer [B][8] of uint64 that the persistent
+ * kernel fills with per-rod cycle counters {total, sweep, algebra, prologue, iterations}. */
+int kr_debug_buffer(kr_handle* h, void* dev_ptr);
 /* CosseratRod.compute_intermediate_terms, cosserat_ode.py:58-78 */
 int kr_set_params(kr_handle* h, const kr_params* p);
 int kr_get_derived(const kr_handle* h, kr_derived* out);
@@ -171,20 +187,30 @@ int kr_residual_batch(kr_handle* h, int64_t B, int scheme, const void* G, const 
  * forward-difference Jacobian instead of MINPACK hybrd; same root), final
  * swept state into state_next.  G[B][6] is read as the initial guess and
  * overwritten with the solution.  tol: stop when |dG|_inf <= tol*max(1,|G|_inf)
- * (<=0 selects 1e-10 for f64, 1e-5 for f32); maxit <= 0 selects 30.
- * status[B], iters[B] (int32) may be NULL. */
+ * (<=0 selects 1e-8 for f64 - the class of the reference's fsolve xtol=1.49e-8 - and 1e-5 for f32); maxit <= 0 selects 30.
+ * status[B], iters[B] (int32) may be NULL.
+ * Initial guess: predictor = 0 starts Newton from the caller's G (the
+ * reference's warm start, knode.py:89); 1 / 2 extrapolate the unknowns linearly /
+ * quadratically in time from state_cur, state_prev (and state_prev2, may be
+ * NULL; it may alias state_next, it is read before anything is written);
+ * -1 = the highest order the given states allow (prev == cur means "no history"). */
 int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, const void* state_cur,
                   void* state_next, void* G, const void* tensions, double tol, int maxit, int32_t* status,
-                  int32_t* iters, int use_nn, int dtype, void* stream);
+                  int32_t* iters, int use_nn, const void* state_prev2, int predictor, int dtype, void* stream);
 
 /* T steps of the above in one call.  ctl[B][T][4]; states[(T+1)][B][N][KR_SLOTS]
  * with states[0] the initial condition (e.g. kr_state_init_straight) - step t
  * writes states[t+1]; if ring != 0, `states` holds only 3 slots used
  * cyclically (slot (t+1)%3) for tip-only runs.  tip[B][T][3] may be NULL.
- * status[B][T] may be NULL.  Replaces knode.simulate (knode.py:55-102). */
+ * status[B][T] may be NULL.  Replaces knode.simulate (knode.py:55-102).
+ * state_prev_init: NULL = the reference's start (y_prev = y before the first
+ * step, knode.py:65-66); otherwise the packed state one step before states[0],
+ * which makes a second call continue a run exactly (it may point into the ring).
+ * When the multiple-shooting kernel applies (see kr_set_option) all T steps run
+ * in ONE launch: every wavefront keeps its rod's history in LDS / registers. */
 int kr_simulate_batch(kr_handle* h, int64_t B, int64_t T, int scheme, const void* ctl, void* states, int ring,
-                      void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn, int dtype,
-                      void* stream);
+                      void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn,
+                      const void* state_prev_init, int dtype, void* stream);
 
 /* ---- KNODE one-step-ahead training path -------------------------------- */
 /* CosseratRodTorch.parallelGetNextSegmentEuler (cosserat_ode_torch.py:401-437)

@@ -2,6 +2,7 @@
 // handle management, parameter derivation (reference cosserat_ode.py:58-78),
 // presets (knode.py:6-53), MLP packing and the dtype dispatch of every call.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "kr_internal.hpp"
@@ -138,12 +139,14 @@ static StepArgs<T> make_args(const kr_handle* h, int64_t B, const void* prev, co
   a.G = (T*)G;
   a.tens = (const T*)tens; a.tens_stride = tens_stride;
   const bool f64 = sizeof(T) == 8;
-  if (!(tol > 0)) tol = f64 ? 1e-10 : 1e-5;
+  if (!(tol > 0)) tol = f64 ? 1e-8 : 1e-5;  // fp64: the class of hybrd's xtol = 1.49e-8 the reference runs with
   a.tol = (T)tol;
   a.tolA = (T)std::sqrt(tol);
   a.fd_eps = f64 ? (T)1e-7 : (T)1e-3;
   a.maxit = maxit > 0 ? maxit : 30;
   a.mode = 0;
+  a.prev2 = nullptr;
+  a.pred_order = 0;
   a.hc1 = (T)h->derived.c1; a.hc2 = (T)h->derived.c2;
   a.st_stride = 1;
   a.tip_stride = 3;
@@ -152,16 +155,39 @@ static StepArgs<T> make_args(const kr_handle* h, int64_t B, const void* prev, co
 
 template <typename T>
 static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, const void* ctl, void* states, int ring,
-                         void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn, hipStream_t s) {
+                         void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn,
+                         const void* prev_init, hipStream_t s) {
   const size_t slot = (size_t)B * h->params.N * KR_SLOTS;
   T* base = (T*)states;
+  {
+    // one launch for all steps when the multiple-shooting kernel applies
+    auto a0 = make_args<T>(h, B, nullptr, nullptr, nullptr, G, ctl, 4, tol, maxit);
+    SimArgs<T> sa{};
+    sa.B = B; sa.T_steps = T_steps; sa.states = base; sa.slot_elems = (int64_t)slot; sa.ring = ring;
+    sa.prev_init = (const T*)prev_init; sa.ctl = (const T*)ctl; sa.G = (T*)G; sa.tip = (T*)tip; sa.status = status;
+    sa.tol = a0.tol; sa.tolA = a0.tolA; sa.fd_eps = a0.fd_eps; sa.hc1 = a0.hc1; sa.hc2 = a0.hc2;
+    sa.maxit = a0.maxit; sa.predictor = h->predictor;
+    sa.dbg = static_cast<unsigned long long*>(h->dbg);
+    const int rc = launch_sim_persistent<T>(h, scheme, use_nn, sa, s);
+    if (rc != 1) {
+      h->last_sim_path = 2;
+      return rc;
+    }
+  }
+  h->last_sim_path = 0;
   for (int64_t t = 0; t < T_steps; ++t) {
-    // knode.py:65-66,76-77: before the first step y_prev = y
+    // knode.py:65-66,76-77: before the first step y_prev = y (unless the caller hands over the state before)
     const int64_t ic = ring ? t % 3 : t;
-    const int64_t ip = t == 0 ? ic : (ring ? (t + 2) % 3 : t - 1);
     const int64_t in = ring ? (t + 1) % 3 : t + 1;
-    auto a = make_args<T>(h, B, base + ip * slot, base + ic * slot, base + in * slot, G, (const T*)ctl + t * 4,
+    const T* pprev = t == 0 ? (prev_init ? (const T*)prev_init : base + ic * slot)
+                            : base + (ring ? (t + 2) % 3 : t - 1) * slot;
+    auto a = make_args<T>(h, B, pprev, base + ic * slot, base + in * slot, G, (const T*)ctl + t * 4,
                           T_steps * 4, tol, maxit);
+    // time extrapolation of the initial guess from the states already computed (order <= h->predictor)
+    int order = t == 0 ? (prev_init ? 1 : 0) : (t == 1 ? (prev_init ? 2 : 1) : 2);
+    if (order > h->predictor) order = h->predictor;
+    if (order == 2) a.prev2 = t == 1 ? (const T*)prev_init : base + (ring ? (t + 1) % 3 : t - 2) * slot;
+    a.pred_order = order;
     if (tip) { a.tip = (T*)tip + t * 3; a.tip_stride = T_steps * 3; }
     if (status) { a.status = status + t; a.st_stride = T_steps; }
     int rc = launch_step<T>(h, scheme, use_nn, a, s);
@@ -257,7 +283,55 @@ int kr_create(const kr_params* p, int device, kr_handle** out) {
   int lds = 0;
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
     h->lds_limit = lds;
+  if (const char* e = std::getenv("KR_MS_MODE")) h->ms_mode = std::atoi(e);
+  if (const char* e = std::getenv("KR_PREDICTOR")) h->predictor = std::atoi(e);
+  if (const char* e = std::getenv("KR_PERSISTENT")) h->persistent = std::atoi(e) ? 1 : 0;
   *out = h;
+  return KR_OK;
+}
+
+int kr_set_option(kr_handle* h, const char* name, int value) {
+  KR_CHECK_H(h);
+  KR_CHECK_PTR(name);
+  const std::string n = name;
+  if (n == "ms_mode") {
+    if (value < -1 || value > 1) { set_error("ms_mode must be -1, 0 or 1"); return KR_E_ARG; }
+    h->ms_mode = value;
+  } else if (n == "ms_batch_limit") {
+    if (value < 0) { set_error("ms_batch_limit must be >= 0"); return KR_E_ARG; }
+    h->ms_batch_limit = value;
+  } else if (n == "persistent") {
+    h->persistent = value ? 1 : 0;
+  } else if (n == "predictor") {
+    if (value < 0 || value > 2) { set_error("predictor must be 0, 1 or 2"); return KR_E_ARG; }
+    h->predictor = value;
+  } else {
+    set_error("unknown option " + n);
+    return KR_E_ARG;
+  }
+  return KR_OK;
+}
+
+int kr_get_option(kr_handle* h, const char* name, int* value) {
+  KR_CHECK_H(h);
+  KR_CHECK_PTR(name);
+  KR_CHECK_PTR(value);
+  const std::string n = name;
+  if (n == "ms_mode") *value = h->ms_mode;
+  else if (n == "ms_batch_limit") *value = h->ms_batch_limit;
+  else if (n == "persistent") *value = h->persistent;
+  else if (n == "predictor") *value = h->predictor;
+  else if (n == "last_sim_path") *value = h->last_sim_path;
+  else {
+    set_error("unknown option " + n);
+    return KR_E_ARG;
+  }
+  return KR_OK;
+}
+
+int kr_debug_buffer(kr_handle* h, void* dev_ptr) {
+  KR_CHECK_H(h);
+  h->dbg = dev_ptr;
   return KR_OK;
 }
 
@@ -438,7 +512,7 @@ int kr_residual_batch(kr_handle* h, int64_t B, int scheme, const void* G, const 
 
 int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, const void* state_cur,
                   void* state_next, void* G, const void* tensions, double tol, int maxit, int32_t* status,
-                  int32_t* iters, int use_nn, int dtype, void* stream) {
+                  int32_t* iters, int use_nn, const void* state_prev2, int predictor, int dtype, void* stream) {
   KR_BATCH_PROLOGUE(B);
   KR_CHECK_PTR(G); KR_CHECK_PTR(state_prev); KR_CHECK_PTR(state_cur); KR_CHECK_PTR(state_next);
   KR_CHECK_PTR(tensions);
@@ -446,25 +520,33 @@ int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, c
     set_error("state_next must not alias state_cur / state_prev");
     return KR_E_ARG;
   }
+  // predictor: -1 = highest order the given history allows, else min(requested, available)
+  int avail = state_prev2 ? 2 : (state_prev != state_cur ? 1 : 0);
+  if (predictor >= 0 && predictor < avail) avail = predictor;
   if (dtype == KR_F32) {
     auto a = make_args<float>(h, B, state_prev, state_cur, state_next, G, tensions, 4, tol, maxit);
     a.status = status; a.iters = iters;
+    a.prev2 = (const float*)state_prev2; a.pred_order = avail;
     return launch_step<float>(h, scheme, use_nn, a, s);
   }
   auto a = make_args<double>(h, B, state_prev, state_cur, state_next, G, tensions, 4, tol, maxit);
   a.status = status; a.iters = iters;
+  a.prev2 = (const double*)state_prev2; a.pred_order = avail;
   return launch_step<double>(h, scheme, use_nn, a, s);
 }
 
 int kr_simulate_batch(kr_handle* h, int64_t B, int64_t T, int scheme, const void* ctl, void* states, int ring, void* G,
-                      void* tip, double tol, int maxit, int32_t* status, int use_nn, int dtype, void* stream) {
+                      void* tip, double tol, int maxit, int32_t* status, int use_nn, const void* state_prev_init,
+                      int dtype, void* stream) {
   KR_BATCH_PROLOGUE(B);
   if (T < 0) { set_error("T < 0"); return KR_E_ARG; }
   if (T == 0) return KR_OK;
   KR_CHECK_PTR(ctl); KR_CHECK_PTR(states); KR_CHECK_PTR(G);
   return dtype == KR_F32
-             ? simulate_impl<float>(h, B, T, scheme, ctl, states, ring, G, tip, tol, maxit, status, use_nn, s)
-             : simulate_impl<double>(h, B, T, scheme, ctl, states, ring, G, tip, tol, maxit, status, use_nn, s);
+             ? simulate_impl<float>(h, B, T, scheme, ctl, states, ring, G, tip, tol, maxit, status, use_nn,
+                                    state_prev_init, s)
+             : simulate_impl<double>(h, B, T, scheme, ctl, states, ring, G, tip, tol, maxit, status, use_nn,
+                                     state_prev_init, s);
 }
 
 }  // extern "C"

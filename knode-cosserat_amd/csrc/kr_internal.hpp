@@ -50,6 +50,13 @@ struct kr_handle {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   int lds_limit = 160 * 1024;
+  int ms_mode = -1;          // multiple-shooting step kernel: -1 auto (by batch size), 0 off, 1 forced
+  int ms_batch_limit = 2048; // auto mode: use it when B <= this
+  int predictor = 2;         // highest extrapolation order kr_simulate_batch may use
+  int last_sim_path = 0;     // what the last kr_simulate_batch did: 0 one single-shooting launch per step,
+                             // 1 one multiple-shooting launch per step, 2 one persistent launch for all steps
+  void* dbg = nullptr;       // diagnostic cycle-counter buffer (kr_debug_buffer)
+  int persistent = 1;        // kr_simulate_batch: run all steps in one launch when the multiple-shooting kernel applies
 };
 
 namespace kr {
@@ -84,6 +91,7 @@ int launch_tip(kr_handle* h, int64_t B, const T* state, T* tip, hipStream_t s);
 template <typename T>
 struct StepArgs {
   int64_t B;
+  const T* prev2;   // optional: state two steps back (quadratic predictor); may alias `next` (read first)
   const T* prev;
   const T* cur;
   T* next;
@@ -102,9 +110,31 @@ struct StepArgs {
   T hc1, hc2;       // history = hc1*cur + hc2*prev (c1, c2 of BDF2, or 1, 0 for explicit history)
   int maxit;
   int mode;         // 0 = Newton step, 1 = single residual sweep
+  int pred_order;   // initial guess: 0 = caller's G / current state, 1 = linear, 2 = quadratic extrapolation in time
 };
 template <typename T>
 int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s);
+
+// persistent multi-step form (kr_ms_impl.hpp)
+template <typename T>
+struct SimArgs {
+  int64_t B, T_steps;
+  T* states;            // [(T+1) or 3][B][N][KR_SLOTS]
+  int64_t slot_elems;   // B*N*KR_SLOTS
+  int ring;
+  const T* prev_init;   // state before states[0] (nullable: y_prev = y, knode.py:65-66)
+  const T* ctl;         // [B][T][4]
+  T* G;                 // [B][6] in/out
+  T* tip;               // [B][T][3] nullable
+  int32_t* status;      // [B][T] nullable
+  T tol, tolA, fd_eps, hc1, hc2;
+  int maxit, predictor;
+  unsigned long long* dbg;  // diagnostic builds (-DKR_MS_STAMPS): [B][8] cycle counters, else unused
+};
+
+// returns 1 when the persistent form does not apply
+template <typename T>
+int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>& a, hipStream_t s);
 
 // kr_ode.hip
 template <typename T>

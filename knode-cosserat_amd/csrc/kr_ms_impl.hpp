@@ -1,0 +1,666 @@
+// kr_ms_impl.hpp - multiple-shooting form of the implicit time step ("latency mode").
+//
+// Why: at the BASELINE batch (1024 rods) the single-shooting kernel keeps only
+// 128 of the chip's 1024 SIMDs busy, each with a dependent chain of
+// (Newton sweeps) x (N-1 grid points).  Here ONE rod owns a whole wavefront:
+// the rod is cut into P = 4 sub-intervals that are integrated concurrently,
+//     interval 0 :  1 + 6  lanes  (unknowns: base wrench G, like single shooting)
+//     interval i :  1 + 16 lanes  (unknowns: the state at the interval's first grid
+//                                  point; p has an identity Jacobian and needs no lane)
+// 7 + 3*17 = 58 lanes, chain length (N-1)/4 per sweep, 1024 wavefronts at B=1024.
+// The discrete equations are the reference's (cosserat_ode.py:198-201 applied on
+// every segment, boundary conditions of :194 and :204-207); only the way the
+// nonlinear system is solved differs: Newton on (G, Y_1..Y_{P-1}) with the
+// continuity conditions  E_i(Y_i) = Y_{i+1}  condensed onto the 6 base unknowns:
+//     dY_1 = c_0 + A_0 dG,  dY_{i+1} = c_i + A_i dY_i   (c_i = E_i - Y_{i+1}, A_i = dE_i/dY_i by
+//     forward differences),  [n;m]-rows of A_{P-1} dY_{P-1} = tip residual  ->  6x6 solve.
+// At acceptance every |dG|, |dY_i| is <= tol, i.e. the stored trajectory satisfies
+// the sweep equations with interface jumps below the solver tolerance - the same
+// accuracy statement as single shooting.
+//
+// The initial guess comes from extrapolating the previous states in time
+// (order 0/1/2), which saves one Newton sweep per step on smooth inputs.
+#pragma once
+#include "kr_sim_impl.hpp"
+
+namespace kr {
+
+constexpr int MS_P = 4;
+constexpr int MS_WPB = 4;  // wavefronts (= rods) per workgroup: the CU puts the 4 waves of a workgroup on its 4 SIMDs
+
+// Rods never interact, so all LDS hand-offs are between lanes of ONE wavefront: order the LDS
+// traffic (s_waitcnt via the workgroup-scope fence) and stop the compiler from moving code across,
+// but do not execute s_barrier - the waves of a workgroup run different numbers of Newton sweeps.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+constexpr int MS_YP = 19;  // length of a state vector in LDS (row order p h n m q w)
+constexpr int MS_NCOL = 6 + 16 * (MS_P - 1);  // Jacobian columns of all intervals, packed
+__device__ __forceinline__ int ms_col0(int iv) { return iv == 0 ? 0 : 6 + 16 * (iv - 1); }
+
+// reference row order r (0..18 = p h n m q w) of the packed slots
+__device__ __forceinline__ int ms_slot_of_yrow(int r) { return r < 13 ? SL_P + r : SL_Q + (r - 13); }
+
+template <typename T>
+__device__ __forceinline__ T extrapolate(int order, T g0, T g1, T g2) {
+  if (order <= 0) return g0;
+  if (order == 1) return T(2) * g0 - g1;
+  return T(3) * (g0 - g1) + g2;
+}
+
+// LDS elements of one rod (a multiple of 4, so every rod's slice stays 16-byte aligned)
+template <typename T, int HS>
+__host__ __device__ inline size_t ms_lds_elems(int N, bool persist) {
+  size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + (MS_YP + 1) * 8 + 48 + WAVE + ((WAVE * MS_YP + 3) & ~3);
+  if (persist) n += (size_t)N * 12 + 3 * MS_P * MS_YP;
+  return (n + 3) & ~size_t(3);
+}
+
+#ifdef KR_MS_STAMPS
+#define KR_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); (var) = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KR_STAMP_ADD(acc, t0) do { unsigned long long _t; KR_STAMP(_t); (acc) += _t - (t0); (t0) = _t; } while (0)
+struct MsStamps { unsigned long long sweep = 0, alg = 0, prep = 0, total = 0; int its = 0; double dn[4] = {0, 0, 0, 0}; };
+#else
+#define KR_STAMP(var) do { } while (0)
+#define KR_STAMP_ADD(acc, t0) do { } while (0)
+struct MsStamps { };
+#endif
+
+// lane roles inside the wavefront
+struct MsRole {
+  int iv, col, s_i, len_i, lmax, comp, sbase, srem;
+  bool idle;
+};
+__device__ __forceinline__ MsRole ms_role(int lane, int N) {
+  MsRole R;
+  R.idle = lane >= 7 + 17 * (MS_P - 1);
+  if (lane < 7) { R.iv = 0; R.col = lane; }
+  else if (!R.idle) { R.iv = 1 + (lane - 7) / 17; R.col = (lane - 7) % 17; }
+  else { R.iv = 0; R.col = 0; }
+  const int nseg = N - 1;
+  R.sbase = nseg / MS_P;
+  R.srem = nseg % MS_P;
+  // interval i covers segments [s_i, s_i + len_i)
+  R.s_i = R.iv * R.sbase + (R.iv < R.srem ? R.iv : R.srem);
+  R.len_i = R.sbase + (R.iv < R.srem ? 1 : 0);
+  R.lmax = R.sbase + (R.srem ? 1 : 0);
+  // perturbed component in row order: interval 0 perturbs n,m (rows 7..12), others h..w (rows 3..18)
+  R.comp = R.col == 0 ? -1 : (R.iv == 0 ? 6 + R.col : 2 + R.col);
+  return R;
+}
+__device__ __forceinline__ int ms_interval_start(int i, int sbase, int srem) { return i * sbase + (i < srem ? i : srem); }
+
+template <typename T>
+struct MsLds {
+  T* hist;  // [N][HS]
+  T* Xs;    // [P][MS_YP]      start states (row order p h n m q w); the unknowns
+  T* Es;    // [64][MS_YP]     end state of every lane's sweep
+  T* IH;    // [64]            1 / forward-difference step of every lane
+  T* XB;    // [MS_YP+1][8]    one condensed block X_g = [a_g | M_g], published row by row
+  T* Tm;    // [6][8]          the 6x7 system for dG
+  T* c12;   // persistent kernel only: [N][12] leading slots (q w v u) of the newest state
+};
+template <typename T, int HS>
+__device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist) {
+  MsLds<T> L;
+  L.hist = smem;
+  L.Xs = L.hist + (size_t)N * HS;
+  // everything accessed with 16-byte vectors sits at a multiple of 4 elements
+  L.XB = L.Xs + ((MS_P * MS_YP + 3) & ~3);
+  L.Tm = L.XB + (MS_YP + 1) * 8;
+  L.IH = L.Tm + 48;
+  L.Es = L.IH + WAVE;
+  L.c12 = persist ? L.Es + ((WAVE * MS_YP + 3) & ~3) : nullptr;
+  return L;
+}
+
+template <typename T>
+struct MsSolveArgs {
+  T* out_rod;   // packed state of this rod to stream the accepted sweep into (may be null)
+  T* tip;       // 3 values (may be null)
+  V3<T> vlast, ulast;
+  T tol, tolA, fd_eps;
+  int maxit;
+};
+
+// Newton iteration on (G, Y_1..Y_{P-1}) for one rod = one wavefront.  On entry L.hist holds the
+// history records and L.Xs the initial guess (visible to all lanes).  Returns the status; `it`
+// = sweeps used.  On exit L.Xs holds the accepted unknowns.
+template <typename T, bool DIAG, int SCHEME, int HS, bool PERSIST>
+__device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MsLds<T>& L, const MsRole& R, int lane,
+                                         const SweepCtx<T, HS>& C, const MsSolveArgs<T>& S, int& it, MsStamps& stamps) {
+  const int N = Pc.N;
+#ifdef KR_MS_STAMPS
+  unsigned long long tq;
+  KR_STAMP(tq);
+#endif
+  const MlpDev<T> Mdummy{};
+  T* Xs = L.Xs; T* Es = L.Es; T* IH = L.IH; T* XB = L.XB; T* Tm = L.Tm;
+  const int iv = R.iv, col = R.col;
+  const bool idle = R.idle;
+  bool storing = false, flush = false;
+  int status = KR_ST_MAXIT;
+  it = 0;
+  T dn_prev = T(-1);  // update norm of the previous iteration (contraction estimate)
+
+  while (true) {
+    // ---- start state of this lane ------------------------------------------
+    T yr[19];
+#pragma unroll
+    for (int r = 0; r < 19; ++r) yr[r] = Xs[iv * MS_YP + r];
+    T hstep = T(1);
+#pragma unroll
+    for (int r = 3; r < 19; ++r) {
+      if (r == R.comp) {
+        hstep = S.fd_eps * fmax(fabs(yr[r]), T(1));
+        yr[r] += hstep;
+      }
+    }
+    RodState<T> y = rows_to_state(yr);
+    const bool st = (storing || flush) && col == 0 && !idle;
+
+    // ---- sweep over this lane's sub-interval --------------------------------
+    T hv[HS];
+    load_hist_vec<T, HS>(C.hbase + (size_t)R.s_i * HS, hv);
+    for (int t = 0; t < R.lmax; ++t) {
+      if (t < R.len_i) {
+        const int j = R.s_i + t;
+        RodState<T> k1;
+        V3<T> v, u;
+        eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, y, hv, k1, v, u);
+        if (st) {
+          T rec[KR_SLOTS];
+          record_from(y, v, u, rec);
+          if (S.out_rod) store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
+          if constexpr (PERSIST) {
+            T lead[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+            store_vec<T, 12>(L.c12 + (size_t)j * 12, lead);
+          }
+        }
+        if constexpr (SCHEME == KR_EULER) {
+          load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hv);
+          y = state_axpy(y, Pc.ds, k1);
+        } else {
+          T hn[HS], hm[HS];
+          load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hn);
+#pragma unroll
+          for (int c = 0; c < HS; ++c) hm[c] = T(0.5) * (hv[c] + hn[c]);
+          RodState<T> k2, k3, k4;
+          V3<T> v2, u2;
+          RodState<T> ya = state_axpy(y, Pc.ds * T(0.5), k1);
+          eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, ya, hm, k2, v2, u2);
+          ya = state_axpy(y, Pc.ds * T(0.5), k2);
+          eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, ya, hm, k3, v2, u2);
+          ya = state_axpy(y, Pc.ds, k3);
+          eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, ya, hn, k4, v2, u2);
+          RodState<T> ksum = state_axpy(k1, T(2), k2);
+          ksum = state_axpy(ksum, T(2), k3);
+          ksum = state_axpy(ksum, T(1), k4);
+          y = state_axpy(y, Pc.ds / T(6), ksum);
+#pragma unroll
+          for (int c = 0; c < HS; ++c) hv[c] = hn[c];
+        }
+      }
+    }
+    if (st && iv == MS_P - 1) {
+      T rec[KR_SLOTS];
+      record_from(y, S.vlast, S.ulast, rec);
+      if (S.out_rod) store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+      if constexpr (PERSIST) {
+        T lead[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+        store_vec<T, 12>(L.c12 + (size_t)(N - 1) * 12, lead);
+      }
+      if (S.tip) { S.tip[0] = y.p.x; S.tip[1] = y.p.y; S.tip[2] = y.p.z; }
+    }
+    if (flush) break;
+    ++it;
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.sweep, tq);
+#endif
+
+    // ---- hand the end states over (one LDS row per lane) ---------------------------
+    {
+      T er[19];
+      state_to_rows(y, er);
+#pragma unroll
+      for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = er[r];
+      IH[lane] = col > 0 ? fast_rcp(hstep) : T(0);
+    }
+    wave_sync();
+
+    // ---- condensation, row per lane ---------------------------------------------------
+    // lane -> (g, r): row r of interval g = 1..P-1.  The lane keeps row r of A_g = dE_g/dY_g
+    // (16 forward-difference columns; the p columns are the identity) in registers, receives
+    // row r of X_g = [a_g | M_g] (dY_g = a_g + M_g dG) and produces row r of
+    // X_{g+1} = [E_g - Y_{g+1} | 0] + A_g X_g, published through one 19x8 LDS tile.
+    const bool rowlane = lane < 19 * (MS_P - 1);
+    const int g = rowlane ? lane / 19 + 1 : 1;
+    const int r = rowlane ? lane - (g - 1) * 19 : 0;
+    const int l0 = 7 + 17 * (g - 1);  // unperturbed lane of interval g
+    const T e0 = Es[l0 * MS_YP + r];
+    T Arow[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Arow[c] = (Es[(l0 + 1 + c) * MS_YP + r] - e0) * IH[l0 + 1 + c];
+    const T cg = g < MS_P - 1 ? e0 - Xs[(g + 1) * MS_YP + r] : T(0);
+    T Xown[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Xown[k] = T(0);
+    if (rowlane && g == 1) {  // X_1 = [E_0 - Y_1 | A_0]
+      const T e00 = Es[0 * MS_YP + r];
+      T x1[8];
+      x1[0] = e00 - Xs[1 * MS_YP + r];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x1[1 + k] = (Es[(1 + k) * MS_YP + r] - e00) * IH[1 + k];
+      x1[7] = T(0);
+      store_vec<T, 8>(XB + r * 8, x1);
+    }
+    for (int stage = 1; stage < MS_P; ++stage) {
+      wave_sync();
+      T Xn[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Xn[k] = T(0);
+      if (rowlane && g == stage) {
+        load_hist_vec<T, 8>(XB + r * 8, Xown);  // row r of X_g: needed for dY_g[r] below
+        Xn[0] = cg;
+        if (r < 3) {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) Xn[k] += Xown[k];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          T xr[8];
+          load_hist_vec<T, 8>(XB + (3 + c) * 8, xr);
+#pragma unroll
+          for (int k = 0; k < 7; ++k) Xn[k] = fma(Arow[c], xr[k], Xn[k]);
+        }
+      }
+      wave_sync();
+      if (rowlane && g == stage) {
+        if (stage < MS_P - 1) {
+          store_vec<T, 8>(XB + r * 8, Xn);
+        } else if (r >= 7 && r < 13) {
+          // tip rows: [n;m](E_{P-1} + A_{P-1}(a + M dG)) = [F_tip; M_tip]  ->  T dG = rhs
+          const int rr = r - 7;
+          const T target = rr < 3 ? Pc.Ftip[rr] : Pc.Mtip[rr - 3];
+          T trow[8];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) trow[k] = Xn[1 + k];
+          trow[6] = target - e0 - (Xn[0] - cg);  // cg is zero for the last interval
+          trow[7] = T(0);
+          store_vec<T, 8>(Tm + rr * 8, trow);
+        }
+      }
+    }
+    wave_sync();
+
+    // ---- 6x6 solve, redundantly in every lane (registers only) -------------------------
+    T d[6];
+    {
+      T a6[6][7];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        T row[8];
+        load_hist_vec<T, 8>(Tm + i * 8, row);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a6[i][k] = row[k];
+      }
+      solve6(a6, d);
+    }
+
+    // ---- updates and convergence --------------------------------------------------------
+    // scaled update norm over every unknown (base wrench and interior states)
+    T dn = T(0);
+    bool finite = true;
+    T upd = T(0);
+    int ui = -1, ur = 0;
+    if (rowlane) {
+      ui = g; ur = r;
+      T s = Xown[0];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s = fma(Xown[1 + k], d[k], s);
+      upd = s;
+    } else if (lane - 19 * (MS_P - 1) < 6) {
+      const int k = lane - 19 * (MS_P - 1);
+      ui = 0; ur = 7 + k;
+      upd = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : k == 3 ? d[3] : k == 4 ? d[4] : d[5];
+    }
+    if (ui >= 0) {
+      dn = fabs(upd) / fmax(fabs(Xs[ui * MS_YP + ur]), T(1));
+      finite = isfinite(upd);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dn = fmax(dn, __shfl_xor(dn, o, WAVE));
+    finite = __all(finite);
+
+    bool done = false;
+    if (!finite) {
+      done = true;
+      status = KR_ST_NONFINITE;
+      flush = !storing;  // nothing consistent stored yet: stream the current iterate once
+    } else if (storing && dn <= S.tol) {
+      done = true;  // the state streamed out by this sweep is the accepted one
+      status = KR_ST_CONVERGED;
+    } else {
+      if (ui >= 0) Xs[ui * MS_YP + ur] += upd;
+      // stream the state out on the sweep that is expected to be accepted: Newton contracts
+      // quadratically, |d_{k+1}| ~ kappa |d_k|^2 with kappa estimated from the last two updates
+      if (predict_final<T>(dn, dn_prev, S.tol, S.tolA)) storing = true;
+      dn_prev = dn;
+      if (it >= S.maxit) {
+        done = true;
+        status = KR_ST_MAXIT;
+        flush = true;  // the unknowns moved after the last stored sweep
+      }
+    }
+    wave_sync();
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.alg, tq);
+    stamps.its += 1;
+    if (it <= 4) stamps.dn[it - 1] = (double)dn;
+#endif
+    if (done && !flush) break;
+    if (done && flush) storing = false;
+  }
+  return status;
+}
+
+template <typename T, int HS>
+__device__ __forceinline__ void ms_ctx_init(const RodConst<T>& Pc, const T* hist, const T* tens4, SweepCtx<T, HS>& C) {
+  C.hbase = hist;
+  C.bufA = nullptr; C.bufB = nullptr; C.astride = 0;
+  C.tf = {T(0), T(0), T(0)};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {  // cosserat_ode.py:195
+    const T tt = tens4[t];
+    C.tf.x += tt * Pc.tdirs[t * 3 + 0];
+    C.tf.y += tt * Pc.tdirs[t * 3 + 1];
+    C.tf.z += tt * Pc.tdirs[t * 3 + 2];
+  }
+  C.fconst = {Pc.rhoAg[0] + C.tf.x, Pc.rhoAg[1] + C.tf.y, Pc.rhoAg[2] + C.tf.z};
+}
+
+// boundary conditions at the base (cosserat_ode.py:194): everything but n, m is prescribed
+template <typename T>
+__device__ __forceinline__ bool ms_base_bc(const RodConst<T>& Pc, int r, T& g) {
+  if (r < 3) { g = Pc.p0[r]; return true; }
+  if (r < 7) { g = Pc.h0[r - 3]; return true; }
+  if (r < 13) return false;
+  if (r < 16) { g = Pc.q0[r - 13]; return true; }
+  g = Pc.w0[r - 16];
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// one time step per launch (kr_step_batch, and kr_simulate_batch when the persistent form does not apply)
+// ---------------------------------------------------------------------------
+template <typename T, bool DIAG, int SCHEME, int HS>
+__global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T> Pc, const StepArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = Pc.N;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = threadIdx.x / WAVE;
+  const int64_t rod = (int64_t)blockIdx.x * MS_WPB + wv;
+  if (rod >= A.B) return;  // whole wavefront; there is no workgroup barrier in this kernel
+  const size_t rod_elems = (size_t)N * KR_SLOTS;
+  const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, false), N, false);
+  const MsRole R = ms_role(lane, N);
+
+  // history terms (knode.py:74-75)
+  for (int j = lane; j < N; j += WAVE) {
+    const size_t off = rod * rod_elems + (size_t)j * KR_SLOTS;
+    build_hist_point<T, HS>(Pc, A.hc1, A.hc2, A.cur + off, A.prev + off, L.hist + (size_t)j * HS);
+  }
+  // initial guess: time extrapolation of the previous states
+  for (int e = lane; e < MS_P * 19; e += WAVE) {
+    const int i = e / 19, r = e - i * 19;
+    const int sj = ms_interval_start(i, R.sbase, R.srem);
+    const size_t off = rod * rod_elems + (size_t)sj * KR_SLOTS + ms_slot_of_yrow(r);
+    T g = extrapolate<T>(A.pred_order, A.cur[off], A.prev[off], A.prev2 ? A.prev2[off] : T(0));
+    if (i == 0) {
+      T bc;
+      if (ms_base_bc(Pc, r, bc)) g = bc;
+      else if (A.pred_order <= 0) g = A.G[rod * 6 + (r - 7)];  // caller's guess unless extrapolated
+    }
+    L.Xs[i * MS_YP + r] = g;
+  }
+  SweepCtx<T, HS> C;
+  ms_ctx_init<T, HS>(Pc, L.hist, A.tens + rod * A.tens_stride, C);
+  MsSolveArgs<T> S;
+  {  // z of the last grid point is never touched by a sweep
+    const T* cl = A.cur + rod * rod_elems + (size_t)(N - 1) * KR_SLOTS;
+    S.vlast = {cl[SL_V], cl[SL_V + 1], cl[SL_V + 2]};
+    S.ulast = {cl[SL_U], cl[SL_U + 1], cl[SL_U + 2]};
+  }
+  S.out_rod = A.next + rod * rod_elems;
+  S.tip = A.tip ? A.tip + rod * A.tip_stride : nullptr;
+  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  wave_sync();
+  int it;
+  MsStamps stamps;
+  const int status = ms_newton<T, DIAG, SCHEME, HS, false>(Pc, L, R, lane, C, S, it, stamps);
+  if (lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * MS_YP + 7 + lane];
+  if (lane == 0) {
+    if (A.status) A.status[rod * A.st_stride] = status;
+    if (A.iters) A.iters[rod * A.st_stride] = it;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// persistent form: one launch runs all T steps of kr_simulate_batch; a wavefront keeps its rod
+// ---------------------------------------------------------------------------
+constexpr int MS_NPL = 2;  // grid points per lane held in registers by the persistent kernel (N <= 128)
+
+template <typename T, bool DIAG, int SCHEME, int HS>
+__global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = Pc.N;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = threadIdx.x / WAVE;
+  const int64_t rod = (int64_t)blockIdx.x * MS_WPB + wv;
+  if (rod >= A.B) return;  // whole wavefront; there is no workgroup barrier in this kernel
+  const size_t rod_elems = (size_t)N * KR_SLOTS;
+  const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, true), N, true);
+  T* Yh = L.c12 + (size_t)N * 12;  // [3][P][MS_YP] interval-start states of the last three time levels
+  const MsRole R = ms_role(lane, N);
+
+  // leading slots (q w v u) of the newest state live in LDS (c12), those of the state before it in
+  // registers (regP), both indexed lane-per-grid-point: the BDF2 history of the next step never
+  // touches HBM
+  T regP[MS_NPL][12];
+  const T* s0 = A.states + rod * rod_elems;
+  const T* sp = A.prev_init ? A.prev_init + rod * rod_elems : s0;
+#pragma unroll
+  for (int q = 0; q < MS_NPL; ++q) {
+    const int j = lane + q * WAVE;
+    if (j < N) {
+      T cv[12];
+      load_hist_vec<T, 12>(s0 + (size_t)j * KR_SLOTS, cv);
+      store_vec<T, 12>(L.c12 + (size_t)j * 12, cv);
+      load_hist_vec<T, 12>(sp + (size_t)j * KR_SLOTS, regP[q]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) regP[q][c] = T(0);
+    }
+  }
+  // interval-start states of states[0] and of the state before it (for the extrapolation)
+  for (int e = lane; e < MS_P * 19; e += WAVE) {
+    const int i = e / 19, r = e - i * 19;
+    const size_t off = (size_t)ms_interval_start(i, R.sbase, R.srem) * KR_SLOTS + ms_slot_of_yrow(r);
+    Yh[(0 * MS_P + i) * MS_YP + r] = s0[off];
+    Yh[(1 * MS_P + i) * MS_YP + r] = sp[off];
+    Yh[(2 * MS_P + i) * MS_YP + r] = sp[off];
+  }
+  MsSolveArgs<T> S;
+  {
+    const T* cl = s0 + (size_t)(N - 1) * KR_SLOTS;
+    S.vlast = {cl[SL_V], cl[SL_V + 1], cl[SL_V + 2]};
+    S.ulast = {cl[SL_U], cl[SL_U + 1], cl[SL_U + 2]};
+  }
+  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  int avail = A.prev_init ? 1 : 0;  // time levels behind states[0] that carry information
+  T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
+  const T* ctl = A.ctl + rod * A.T_steps * 4;
+  T tens[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tens[k] = ctl[k];
+  wave_sync();
+
+  MsStamps stamps;
+#ifdef KR_MS_STAMPS
+  unsigned long long t_begin, tp;
+  KR_STAMP(t_begin);
+#endif
+  for (int64_t t = 0; t < A.T_steps; ++t) {
+#ifdef KR_MS_STAMPS
+    KR_STAMP(tp);
+#endif
+    // ---- history records from c12 (newest) and regP (the one before) ----------
+#pragma unroll
+    for (int q = 0; q < MS_NPL; ++q) {
+      const int j = lane + q * WAVE;
+      if (j < N) {
+        T cv[12];
+        load_hist_vec<T, 12>(L.c12 + (size_t)j * 12, cv);
+        build_hist_regs<T, HS>(Pc, A.hc1, A.hc2, cv, regP[q], L.hist + (size_t)j * HS);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) regP[q][c] = cv[c];
+      }
+    }
+    // ---- initial guess ----------------------------------------------------------
+    int order = avail < A.predictor ? avail : A.predictor;
+    for (int e = lane; e < MS_P * 19; e += WAVE) {
+      const int i = e / 19, r = e - i * 19;
+      T g = extrapolate<T>(order, Yh[(0 * MS_P + i) * MS_YP + r], Yh[(1 * MS_P + i) * MS_YP + r],
+                           Yh[(2 * MS_P + i) * MS_YP + r]);
+      if (i == 0) {
+        T bc;
+        if (ms_base_bc(Pc, r, bc)) g = bc;
+      }
+      L.Xs[i * MS_YP + r] = g;
+    }
+    wave_sync();
+    if (order <= 0 && lane < 6) L.Xs[0 * MS_YP + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
+    SweepCtx<T, HS> C;
+    ms_ctx_init<T, HS>(Pc, L.hist, tens, C);
+    if (t + 1 < A.T_steps) {  // next step's tensions: issued now, consumed after this step's solve
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tens[k] = ctl[(t + 1) * 4 + k];
+    }
+    const int64_t inx = A.ring ? (t + 1) % 3 : t + 1;
+    S.out_rod = A.states + inx * A.slot_elems + rod * rod_elems;
+    S.tip = A.tip ? A.tip + (rod * A.T_steps + t) * 3 : nullptr;
+    wave_sync();
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.prep, tp);
+#endif
+    int it;
+    const int status = ms_newton<T, DIAG, SCHEME, HS, true>(Pc, L, R, lane, C, S, it, stamps);
+    if (lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
+    // ---- shift the time levels of the unknowns ------------------------------------
+    for (int e = lane; e < MS_P * 19; e += WAVE) {
+      const int i = e / 19, r = e - i * 19;
+      const T y1 = Yh[(1 * MS_P + i) * MS_YP + r], y0 = Yh[(0 * MS_P + i) * MS_YP + r];
+      Yh[(2 * MS_P + i) * MS_YP + r] = y1;
+      Yh[(1 * MS_P + i) * MS_YP + r] = y0;
+      Yh[(0 * MS_P + i) * MS_YP + r] = L.Xs[i * MS_YP + r];
+    }
+    if (lane < 6) Gguess = L.Xs[0 * MS_YP + 7 + lane];
+    if (avail < 2) ++avail;
+    wave_sync();
+  }
+  if (lane < 6) A.G[rod * 6 + lane] = Gguess;
+#ifdef KR_MS_STAMPS
+  if (lane == 0 && A.dbg) {
+    unsigned long long te;
+    KR_STAMP(te);
+    unsigned long long* d = A.dbg + rod * 8;
+    d[0] = te - t_begin; d[1] = stamps.sweep; d[2] = stamps.alg; d[3] = stamps.prep; d[4] = (unsigned long long)stamps.its;
+    for (int k = 0; k < 3; ++k) d[5 + k] = (unsigned long long)__double_as_longlong(stamps.dn[k]);
+  }
+#endif
+}
+
+template <typename T, int HS>
+static size_t ms_lds_bytes(int N, bool persist = false) {
+  return sizeof(T) * ms_lds_elems<T, HS>(N, persist) * MS_WPB;
+}
+
+template <typename T, bool DIAG, int SCHEME>
+static int launch_ms_inst(const RodConst<T>& P, const StepArgs<T>& a, hipStream_t s) {
+  auto kern = ms_step_kernel<T, DIAG, SCHEME, hs_phys<T>()>;
+  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N);
+  static thread_local size_t configured = 0;
+  if (smem > 48 * 1024 && smem > configured) {
+    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    configured = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+// true if the multiple-shooting kernel can and should take this call
+template <typename T>
+static bool ms_eligible(kr_handle* h, int use_nn, const StepArgs<T>& a) {
+  const RodConst<T>& P = consts<T>(h);
+  if (use_nn || a.mode != 0) return false;
+  if (h->ms_mode == 0) return false;
+  if (P.N - 1 < 2 * MS_P) return false;                 // too few segments to cut
+  if (ms_lds_bytes<T, hs_phys<T>()>(P.N) > (size_t)h->lds_limit) return false;
+  if (h->ms_mode == 1) return true;                     // forced
+  return a.B <= (int64_t)h->ms_batch_limit;             // auto: latency mode for small batches
+}
+
+template <typename T>
+static int launch_ms(kr_handle* h, int scheme, const StepArgs<T>& a, hipStream_t s) {
+  const RodConst<T>& P = consts<T>(h);
+  h->last_sim_path = 1;
+  if (scheme == KR_EULER)
+    return P.diag ? launch_ms_inst<T, true, KR_EULER>(P, a, s) : launch_ms_inst<T, false, KR_EULER>(P, a, s);
+  if (scheme == KR_RK4)
+    return P.diag ? launch_ms_inst<T, true, KR_RK4>(P, a, s) : launch_ms_inst<T, false, KR_RK4>(P, a, s);
+  set_error("unknown scheme");
+  return KR_E_ARG;
+}
+
+template <typename T, bool DIAG, int SCHEME>
+static int launch_ms_sim_inst(const RodConst<T>& P, const SimArgs<T>& a, hipStream_t s) {
+  auto kern = ms_sim_kernel<T, DIAG, SCHEME, hs_phys<T>()>;
+  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, true);
+  static thread_local size_t configured = 0;
+  if (smem > 48 * 1024 && smem > configured) {
+    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    configured = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+// returns 1 when the persistent form does not apply (caller falls back to one launch per step)
+template <typename T>
+int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>& a, hipStream_t s) {
+  const RodConst<T>& P = consts<T>(h);
+  if (use_nn || h->ms_mode == 0 || h->persistent == 0) return 1;
+  if (P.N - 1 < 2 * MS_P || P.N > MS_NPL * WAVE) return 1;
+  if (ms_lds_bytes<T, hs_phys<T>()>(P.N, true) > (size_t)h->lds_limit) return 1;
+  if (h->ms_mode != 1 && a.B > (int64_t)h->ms_batch_limit) return 1;
+  if (scheme == KR_EULER)
+    return P.diag ? launch_ms_sim_inst<T, true, KR_EULER>(P, a, s) : launch_ms_sim_inst<T, false, KR_EULER>(P, a, s);
+  if (scheme == KR_RK4)
+    return P.diag ? launch_ms_sim_inst<T, true, KR_RK4>(P, a, s) : launch_ms_sim_inst<T, false, KR_RK4>(P, a, s);
+  set_error("unknown scheme");
+  return KR_E_ARG;
+}
+template int launch_sim_persistent<KR_SIM_T>(kr_handle*, int, int, const SimArgs<KR_SIM_T>&, hipStream_t);
+
+KR_INST(KR_SIM_T)
+
+}  // namespace kr

@@ -1,3 +1,3 @@
 // float instantiation of the simulation kernels
 #define KR_SIM_T float
-#include "kr_sim_impl.hpp"
+#include "kr_ms_impl.hpp"

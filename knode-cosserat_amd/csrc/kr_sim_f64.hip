@@ -1,3 +1,3 @@
 // double instantiation of the simulation kernels
 #define KR_SIM_T double
-#include "kr_sim_impl.hpp"
+#include "kr_ms_impl.hpp"

@@ -73,6 +73,22 @@ __device__ __forceinline__ void store_record(T* dst, const T (&rec)[KR_SLOTS]) {
   }
 }
 
+// n values (a multiple of the 16-byte vector width) to a 16-byte aligned destination
+template <typename T, int NV>
+__device__ __forceinline__ void store_vec(T* dst, const T (&v)[NV]) {
+  using V = typename Vec16<T>::type;
+  constexpr int n = Vec16<T>::n;
+  static_assert(NV % n == 0, "vector store needs a multiple of 16 bytes");
+  V* d = reinterpret_cast<V*>(dst);
+#pragma unroll
+  for (int c = 0; c < NV / n; ++c) {
+    V x;
+#pragma unroll
+    for (int e = 0; e < n; ++e) x[e] = v[c * n + e];
+    d[c] = x;
+  }
+}
+
 template <typename T, int HS>
 __device__ __forceinline__ void load_hist_vec(const T* src, T (&hv)[HS]) {
   if constexpr (HS % Vec16<T>::n == 0) {
@@ -96,7 +112,10 @@ __device__ __forceinline__ void load_hist_vec(const T* src, T (&hv)[HS]) {
 //   HS == HS_PHYS (20): 18..19 padding
 //   HS == HS_NNH  (32): 18..30 history of p h n m (MLP input when nn_input_history), 31 padding
 constexpr int HS_PHYS = 20;
+constexpr int HS_PHYS64 = 18;  // fp64: 18 doubles are already a multiple of 16 bytes, no padding
 constexpr int HS_NNH = 32;
+template <typename T>
+constexpr int hs_phys() { return sizeof(T) == 8 ? HS_PHYS64 : HS_PHYS; }
 
 template <typename T, int HS>
 __device__ __forceinline__ RodHist<T> hist_from(const T (&hv)[HS]) {
@@ -138,7 +157,7 @@ __device__ __forceinline__ void build_hist_point(const RodConst<T>& P, T hc1, T 
 #pragma unroll
     for (int k = 0; k < 13; ++k) hv[18 + k] = raw[12 + k];
     hv[31] = T(0);
-  } else {
+  } else if constexpr (HS > 18) {
     hv[18] = T(0);
     hv[19] = T(0);
   }
@@ -152,6 +171,18 @@ __device__ __forceinline__ void build_hist_point(const RodConst<T>& P, T hc1, T 
     for (int e = 0; e < n; ++e) v[e] = hv[k * n + e];
     d[k] = v;
   }
+}
+
+// Will the next Newton sweep be the accepted one?  dn / dn_prev are the scaled update norms of
+// this and the previous iteration.  Quadratic contraction |d_{k+1}| ~ kappa |d_k|^2, kappa from the
+// last two updates (capped at 1 = the conservative sqrt(tol) rule when no estimate exists yet).
+template <typename T>
+__device__ __forceinline__ bool predict_final(T dn, T dn_prev, T tol, T tolA) {
+  if (dn <= tolA) return true;
+  if (!(dn_prev > T(0)) || !(dn < dn_prev)) return false;
+  T kappa = dn / (dn_prev * dn_prev);
+  kappa = fmin(fmax(kappa, T(1e-3)), T(1));
+  return T(4) * kappa * dn * dn <= tol;
 }
 
 // 6x6 solve, Gaussian elimination with partial pivoting on static indices.
@@ -303,6 +334,16 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
   T G[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) G[k] = A.G[rod * 6 + k];
+  if (A.pred_order > 0) {
+    // G of earlier steps = n, m at the base of the stored states; extrapolate in time
+    const size_t o0 = rod * rod_elems + SL_N;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const T g0 = A.cur[o0 + k], g1 = A.prev[o0 + k];
+      const T g2 = A.pred_order > 1 ? A.prev2[o0 + k] : T(0);
+      G[k] = A.pred_order > 1 ? T(3) * (g0 - g1) + g2 : T(2) * g0 - g1;
+    }
+  }
   C.tf = {T(0), T(0), T(0)};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {  // cosserat_ode.py:195
@@ -327,6 +368,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
   bool done = false, storing = (A.mode == 1), stored = false, flush = false;
   int status = KR_ST_MAXIT;
   int it = 0;
+  T dn_prev = T(-1);
 
   while (true) {
     // ---- one spatial sweep, all 64 lanes ----------------------------------
@@ -437,7 +479,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
       } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) G[k] -= d[k];
-        if (dn <= A.tolA * gn) storing = true;
+        if (predict_final<T>(dn / gn, dn_prev, A.tol, A.tolA)) storing = true;
+        dn_prev = dn / gn;
         stored = false;
         if (it >= A.maxit) {
           done = true;
@@ -459,6 +502,29 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
     if (A.status) A.status[rod * A.st_stride] = status;
     if (A.iters) A.iters[rod * A.st_stride] = it;
   }
+}
+
+// same from register copies of the twelve leading slots (q w v u) of the two time levels
+template <typename T, int HS>
+__device__ __forceinline__ void build_hist_regs(const RodConst<T>& P, T hc1, T hc2, const T (&cv)[12], const T (&pv)[12],
+                                                T* dst) {
+  static_assert(HS == HS_PHYS || HS == HS_PHYS64, "the register form carries the physics history only");
+  T hv[HS];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) hv[k] = hc1 * cv[k] + hc2 * pv[k];
+  RodHist<T> h;
+  h.qh = {hv[0], hv[1], hv[2]};
+  h.wh = {hv[3], hv[4], hv[5]};
+  h.vh = {hv[6], hv[7], hv[8]};
+  h.uh = {hv[9], hv[10], hv[11]};
+  hist_derive(P, h);
+  hv[12] = h.av.x; hv[13] = h.av.y; hv[14] = h.av.z;
+  hv[15] = h.au.x; hv[16] = h.au.y; hv[17] = h.au.z;
+  if constexpr (HS > 18) {
+    hv[18] = T(0);
+    hv[19] = T(0);
+  }
+  store_vec<T, HS>(dst, hv);
 }
 
 // history into global scratch when it does not fit in LDS
@@ -532,17 +598,23 @@ static int launch_step_mem(kr_handle* h, StepArgs<T> a, hipStream_t s) {
 
 template <typename T, int SCHEME>
 static int launch_step_nn(kr_handle* h, int use_nn, const StepArgs<T>& a, hipStream_t s) {
-  if (!use_nn) return launch_step_mem<T, SCHEME, false, HS_PHYS>(h, a, s);
+  if (!use_nn) return launch_step_mem<T, SCHEME, false, hs_phys<T>()>(h, a, s);
   if (mlpdev<T>(h).n_layers <= 0) {
     set_error("use_nn requested but no MLP was set (kr_set_mlp)");
     return KR_E_STATE;
   }
   if (h->params.nn_input_history) return launch_step_mem<T, SCHEME, true, HS_NNH>(h, a, s);
-  return launch_step_mem<T, SCHEME, true, HS_PHYS>(h, a, s);
+  return launch_step_mem<T, SCHEME, true, hs_phys<T>()>(h, a, s);
 }
 
 template <typename T>
+static bool ms_eligible(kr_handle* h, int use_nn, const StepArgs<T>& a);
+template <typename T>
+static int launch_ms(kr_handle* h, int scheme, const StepArgs<T>& a, hipStream_t s);
+
+template <typename T>
 int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s) {
+  if (ms_eligible<T>(h, use_nn, a)) return launch_ms<T>(h, scheme, a, s);
   if (scheme == KR_EULER) return launch_step_nn<T, KR_EULER>(h, use_nn, a, s);
   if (scheme == KR_RK4) return launch_step_nn<T, KR_RK4>(h, use_nn, a, s);
   set_error("unknown scheme");
@@ -690,6 +762,5 @@ int launch_tip(kr_handle* h, int64_t B, const T* state, T* tip, hipStream_t s) {
   template int launch_unpack<T>(kr_handle*, int64_t, const T*, T*, T*, hipStream_t);            \
   template int launch_unpack50<T>(kr_handle*, int64_t, const T*, const T*, const T*, T*, hipStream_t); \
   template int launch_tip<T>(kr_handle*, int64_t, const T*, T*, hipStream_t);
-KR_INST(KR_SIM_T)
 
 }  // namespace kr

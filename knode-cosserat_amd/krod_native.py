@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libknode_rod.so")
+LIB_PATH = os.environ.get("KR_LIB_PATH") or os.path.join(_HERE, "lib", "libknode_rod.so")
 
 KR_SLOTS = 28
 KR_F32, KR_F64 = 0, 1
@@ -60,6 +60,9 @@ _PROTOS = {
     "kr_apply_preset": (_int, [C.POINTER(KrParams), C.c_char_p]),
     "kr_create": (_int, [C.POINTER(KrParams), _int, C.POINTER(_vp)]),
     "kr_destroy": (_int, [_vp]),
+    "kr_set_option": (_int, [_vp, C.c_char_p, _int]),
+    "kr_get_option": (_int, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
+    "kr_debug_buffer": (_int, [_vp, _vp]),
     "kr_set_params": (_int, [_vp, C.POINTER(KrParams)]),
     "kr_get_derived": (_int, [_vp, C.POINTER(KrDerived)]),
     "kr_derive": (_int, [C.POINTER(KrParams), C.POINTER(KrDerived)]),
@@ -72,8 +75,8 @@ _PROTOS = {
     "kr_state_unpack50": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "kr_state_tip": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
     "kr_residual_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
-    "kr_step_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp, _vp, _int, _int, _vp]),
-    "kr_simulate_batch": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, C.c_double, _int, _vp, _int, _int, _vp]),
+    "kr_step_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp, _vp, _int, _vp, _int, _int, _vp]),
+    "kr_simulate_batch": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, C.c_double, _int, _vp, _int, _vp, _int, _vp]),
     "kr_next_segment_physics": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "kr_mlp_ws_bytes": (C.c_size_t, [_int, C.POINTER(C.c_int32), _i64]),
     "kr_mlp_forward": (_int, [_vp, _i64, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), C.POINTER(_vp), _vp, _int, _vp, _vp, _vp]),
@@ -288,15 +291,23 @@ class Handle:
         return out
 
     def step(self, prev, cur, nxt, G, tensions, scheme=KR_EULER, tol=0.0, maxit=0, status=None, iters=None,
-             use_nn=False):
+             use_nn=False, prev2=None, predictor=-1):
         B = G.shape[0]
         check(self.lib.kr_step_batch(self._h, B, scheme, _ptr(prev), _ptr(cur), _ptr(nxt), _ptr(G), _ptr(tensions),
                                      float(tol), int(maxit), _ptr(status), _ptr(iters), int(bool(use_nn)),
-                                     dtype_code(G.dtype), _stream()))
+                                     _ptr(prev2), int(predictor), dtype_code(G.dtype), _stream()))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        check(self.lib.kr_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def set_option(self, name: str, value: int):
+        check(self.lib.kr_set_option(self._h, name.encode(), int(value)))
 
     def simulate(self, ctl, states, G, ring=False, tip=None, status=None, scheme=KR_EULER, tol=0.0, maxit=0,
-                 use_nn=False):
+                 use_nn=False, prev_init=None):
         B, T = ctl.shape[0], ctl.shape[1]
         check(self.lib.kr_simulate_batch(self._h, B, T, scheme, _ptr(ctl), _ptr(states), int(bool(ring)), _ptr(G),
                                          _ptr(tip), float(tol), int(maxit), _ptr(status), int(bool(use_nn)),
-                                         dtype_code(ctl.dtype), _stream()))
+                                         _ptr(prev_init), dtype_code(ctl.dtype), _stream()))

@@ -16,7 +16,10 @@ r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediat
 h = r._native()
 dev = "cuda:0"
 ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 1235), device=dev)
-for dt, tols in ((torch.float64, (1e-6, 1e-8, 1e-10, 1e-12)), (torch.float32, (1e-4, 1e-5, 1e-6))):
+import itertools
+for (dt, tols), (ms, pred) in itertools.product(((torch.float64, (1e-8, 1e-10)), (torch.float32, (1e-5,))),
+                                                ((0, 0), (0, 2), (1, 0), (1, 1), (1, 2))):
+    h.set_option("ms_mode", ms); h.set_option("predictor", pred)
     ref_tip = None
     for tol in tols:
         c = ctl.to(dt).contiguous()
@@ -27,12 +30,13 @@ for dt, tols in ((torch.float64, (1e-6, 1e-8, 1e-10, 1e-12)), (torch.float32, (1
         cs = [c[:, t].contiguous() for t in range(T)]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for t in range(T):
-            h.step(st[(t + 2) % 3 if t else 0], st[t % 3], st[(t + 1) % 3], G, cs[t], tol=tol, status=sts[t], iters=its[t])
+            h.step(st[(t + 2) % 3 if t else 0], st[t % 3], st[(t + 1) % 3], G, cs[t], tol=tol, status=sts[t], iters=its[t],
+                   prev2=st[(t + 1) % 3] if t >= 2 else None, predictor=min(pred, t))
         torch.cuda.synchronize(); el = time.perf_counter() - t0
         tip = h.tip(st[T % 3]).cpu().numpy()
         if ref_tip is None and dt == torch.float64: pass
         it = its.cpu().numpy()
         hist = np.bincount(it[10:].ravel(), minlength=8)
         wave_max = it[10:].reshape(T - 10, -1, 8).max(axis=2).mean() if B % 8 == 0 else -1
-        print(f"{str(dt):14s} tol={tol:7.0e} ms/step={el/T*1e3:7.3f} mean_it={it[10:].mean():.2f} wave_max_it={wave_max:.2f} "
+        print(f"ms={ms} pred={pred} {str(dt):14s} tol={tol:7.0e} ms/step={el/T*1e3:7.3f} mean_it={it[10:].mean():.2f} wave_max_it={wave_max:.2f} "
               f"hist(it)={hist[:9].tolist()} bad={int((sts!=0).sum())} tip0={tip[0]}")

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): per-phase cycle counters of the persistent multiple-shooting kernel.
+Needs the diagnostic library: KR_LIB_PATH=knode-cosserat_amd/lib/dbg/libknode_rod.so"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "knode-cosserat_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import cosserat_oracle as orc, krod_native as kn
+from cosserat_ode import CosseratRod
+from knode import setup_robot
+B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 100, 120
+dev = "cuda:0"; dt = torch.float64
+r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
+h = r._native(); h.set_option("ms_mode", 1); h.set_option("persistent", 1)
+dbg = torch.zeros((B, 8), dtype=torch.int64, device=dev)
+kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
+ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 1235), device=dev).contiguous()
+for pred in (0, 2):
+    h.set_option("predictor", pred)
+    st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
+    h.simulate(ctl[:, :21].contiguous(), st, G, ring=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    h.simulate(ctl, st, G, ring=True, prev_init=st[2])
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    d = dbg.cpu().numpy().astype(np.float64)
+    tot, sw, al, pr, its = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]
+    print(f"pred={pred}: wall {el/T*1e6:.1f} us/step; s_memtime ticks per step: total mean {tot.mean()/T:.0f} max {tot.max()/T:.0f} | "
+          f"sweep {sw.mean()/T:.0f} alg {al.mean()/T:.0f} prep {pr.mean()/T:.0f} | its/step mean {its.mean()/T:.2f} max {its.max()/T:.2f} | "
+          f"per-iteration sweep {sw.sum()/its.sum():.0f} alg {al.sum()/its.sum():.0f} ticks; tick rate {tot.max()/el/1e6:.1f} MHz")
+    dn = dbg[:, 5:8].cpu().numpy().view(np.float64)
+    its_rod = its / T
+    order = np.argsort(-its_rod)
+    print("   worst rods (its/step, last step dn1 dn2 dn3):")
+    for b in order[:6]: print(f"     rod {b}: {its_rod[b]:.2f}  {dn[b,0]:.1e} {dn[b,1]:.1e} {dn[b,2]:.1e}")
+    print("   best rods:")
+    for b in order[-3:]: print(f"     rod {b}: {its_rod[b]:.2f}  {dn[b,0]:.1e} {dn[b,1]:.1e} {dn[b,2]:.1e}")
+    print("   dn1 quantiles", np.quantile(dn[:,0],[0.5,0.9,0.99,1.0]), " dn2", np.quantile(dn[:,1],[0.5,0.9,0.99,1.0]), " dn3", np.quantile(dn[:,2],[0.5,0.9,0.99,1.0]))
