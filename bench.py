@@ -102,17 +102,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    # one rank per GPU; KR_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the
+    # multi-rank code path on a 1-GPU box (collectives then run on CPU tensors)
+    backend = os.environ.get("KR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = f"cuda:{dev_index}"
+    cdev = dev if backend == "nccl" else "cpu"  # where the collective's tensors live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     B, N, K, W = args.batch, args.nodes_per_rod, args.steps, args.warmup
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esize = 8 if args.dtype == "f64" else 4
 
-    robot = CosseratRod(use_fsolve=True, device=local_rank)
+    robot = CosseratRod(use_fsolve=True, device=dev_index)
     setup_robot(robot)
     robot.N = N
     robot.compute_intermediate_terms()
@@ -153,7 +162,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     if world > 1:
         dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = ev0.elapsed_time(ev1)  # duration of the K-step region on the launch stream (HIP events)

@@ -49,10 +49,14 @@ __device__ __forceinline__ T extrapolate(int order, T g0, T g1, T g2) {
   return T(3) * (g0 - g1) + g2;
 }
 
+enum : int {
+  CD_P0 = 0, CD_H0 = 3, CD_Q0 = 7, CD_W0 = 10, CD_FTIP = 13, CD_MTIP = 16, CD_TDIRS = 19, CD_RHOAG = 31,
+  CD_KSEI = 34, CD_KSEV = 43, CD_BSE = 46, CD_KBTI = 55, CD_BBT = 64, CD_SIZE = 76
+};
 // LDS elements of one rod (a multiple of 4, so every rod's slice stays 16-byte aligned)
 template <typename T, int HS>
 __host__ __device__ inline size_t ms_lds_elems(int N, bool persist) {
-  size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + (MS_YP + 1) * 8 + 48 + WAVE + ((WAVE * MS_YP + 3) & ~3);
+  size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + (MS_YP + 1) * 8 + 48 + CD_SIZE + WAVE + ((WAVE * MS_YP + 3) & ~3);
   if (persist) n += (size_t)N * 12 + 3 * MS_P * MS_YP;
   return (n + 3) & ~size_t(3);
 }
@@ -66,6 +70,66 @@ struct MsStamps { unsigned long long sweep = 0, alg = 0, prep = 0, total = 0; in
 #define KR_STAMP_ADD(acc, t0) do { } while (0)
 struct MsStamps { };
 #endif
+
+// Per-step ("cold") rod parameters live in a small LDS table so that only the ~15 doubles the sweep
+// itself needs occupy scalar registers (keeping all of RodConst live across the time-step loop
+// made the compiler spill SGPRs to VGPR lanes: 48 v_readlane per grid point).
+template <typename T>
+__device__ __forceinline__ void ms_cold_fill(const RodConst<T>& Pc, T* cold, int lane) {
+  // one value per lane and round; the table is read back by everybody after a wave_sync
+  for (int k = lane; k < CD_SIZE; k += WAVE) {
+    T v;
+    if (k < CD_H0) v = Pc.p0[k - CD_P0];
+    else if (k < CD_Q0) v = Pc.h0[k - CD_H0];
+    else if (k < CD_W0) v = Pc.q0[k - CD_Q0];
+    else if (k < CD_FTIP) v = Pc.w0[k - CD_W0];
+    else if (k < CD_MTIP) v = Pc.Ftip[k - CD_FTIP];
+    else if (k < CD_TDIRS) v = Pc.Mtip[k - CD_MTIP];
+    else if (k < CD_RHOAG) v = Pc.tdirs[k - CD_TDIRS];
+    else if (k < CD_KSEI) v = Pc.rhoAg[k - CD_RHOAG];
+    else if (k < CD_KSEV) v = Pc.Ksei[k - CD_KSEI];
+    else if (k < CD_BSE) v = Pc.Kse_vstar[k - CD_KSEV];
+    else if (k < CD_KBTI) v = Pc.Bse[k - CD_BSE];
+    else if (k < CD_BBT) v = Pc.Kbti[k - CD_KBTI];
+    else v = Pc.Bbt[k - CD_BBT];
+    cold[k] = v;
+  }
+}
+template <typename T>
+__device__ __forceinline__ V3<T> cold_matvec(const T* A, V3<T> x) {
+  return {A[0] * x.x + A[1] * x.y + A[2] * x.z, A[3] * x.x + A[4] * x.y + A[5] * x.z,
+          A[6] * x.x + A[7] * x.y + A[8] * x.z};
+}
+// hist_derive with the matrices read from the cold table
+template <typename T>
+__device__ __forceinline__ void hist_derive_cold(const T* cold, RodHist<T>& h) {
+  V3<T> bv = cold_matvec(cold + CD_BSE, h.vh);
+  V3<T> t{cold[CD_KSEV] - bv.x, cold[CD_KSEV + 1] - bv.y, cold[CD_KSEV + 2] - bv.z};
+  h.av = cold_matvec(cold + CD_KSEI, t);
+  V3<T> bu = cold_matvec(cold + CD_BBT, h.uh);
+  V3<T> t2 = cold_matvec(cold + CD_KBTI, bu);
+  h.au = {-t2.x, -t2.y, -t2.z};
+}
+template <typename T, int HS>
+__device__ __forceinline__ void build_hist_cold(const T* cold, T hc1, T hc2, const T (&cv)[12], const T (&pv)[12],
+                                                T* dst) {
+  T hv[HS];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) hv[k] = hc1 * cv[k] + hc2 * pv[k];
+  RodHist<T> h;
+  h.qh = {hv[0], hv[1], hv[2]};
+  h.wh = {hv[3], hv[4], hv[5]};
+  h.vh = {hv[6], hv[7], hv[8]};
+  h.uh = {hv[9], hv[10], hv[11]};
+  hist_derive_cold(cold, h);
+  hv[12] = h.av.x; hv[13] = h.av.y; hv[14] = h.av.z;
+  hv[15] = h.au.x; hv[16] = h.au.y; hv[17] = h.au.z;
+  if constexpr (HS > 18) {
+    hv[18] = T(0);
+    hv[19] = T(0);
+  }
+  store_vec<T, HS>(dst, hv);
+}
 
 // lane roles inside the wavefront
 struct MsRole {
@@ -99,6 +163,7 @@ struct MsLds {
   T* IH;    // [64]            1 / forward-difference step of every lane
   T* XB;    // [MS_YP+1][8]    one condensed block X_g = [a_g | M_g], published row by row
   T* Tm;    // [6][8]          the 6x7 system for dG
+  T* cold;  // [CD_SIZE]       per-step parameters (see ms_cold_fill)
   T* c12;   // persistent kernel only: [N][12] leading slots (q w v u) of the newest state
 };
 template <typename T, int HS>
@@ -109,7 +174,8 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist) {
   // everything accessed with 16-byte vectors sits at a multiple of 4 elements
   L.XB = L.Xs + ((MS_P * MS_YP + 3) & ~3);
   L.Tm = L.XB + (MS_YP + 1) * 8;
-  L.IH = L.Tm + 48;
+  L.cold = L.Tm + 48;
+  L.IH = L.cold + CD_SIZE;
   L.Es = L.IH + WAVE;
   L.c12 = persist ? L.Es + ((WAVE * MS_YP + 3) & ~3) : nullptr;
   return L;
@@ -286,7 +352,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MsLds<T>& 
         } else if (r >= 7 && r < 13) {
           // tip rows: [n;m](E_{P-1} + A_{P-1}(a + M dG)) = [F_tip; M_tip]  ->  T dG = rhs
           const int rr = r - 7;
-          const T target = rr < 3 ? Pc.Ftip[rr] : Pc.Mtip[rr - 3];
+          const T target = L.cold[CD_FTIP + rr];  // F_tip (3) and M_tip (3) are adjacent
           T trow[8];
 #pragma unroll
           for (int k = 0; k < 6; ++k) trow[k] = Xn[1 + k];
@@ -370,28 +436,26 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MsLds<T>& 
 }
 
 template <typename T, int HS>
-__device__ __forceinline__ void ms_ctx_init(const RodConst<T>& Pc, const T* hist, const T* tens4, SweepCtx<T, HS>& C) {
+__device__ __forceinline__ void ms_ctx_init(const T* cold, const T* hist, const T* tens4, SweepCtx<T, HS>& C) {
   C.hbase = hist;
   C.bufA = nullptr; C.bufB = nullptr; C.astride = 0;
   C.tf = {T(0), T(0), T(0)};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {  // cosserat_ode.py:195
     const T tt = tens4[t];
-    C.tf.x += tt * Pc.tdirs[t * 3 + 0];
-    C.tf.y += tt * Pc.tdirs[t * 3 + 1];
-    C.tf.z += tt * Pc.tdirs[t * 3 + 2];
+    C.tf.x += tt * cold[CD_TDIRS + t * 3 + 0];
+    C.tf.y += tt * cold[CD_TDIRS + t * 3 + 1];
+    C.tf.z += tt * cold[CD_TDIRS + t * 3 + 2];
   }
-  C.fconst = {Pc.rhoAg[0] + C.tf.x, Pc.rhoAg[1] + C.tf.y, Pc.rhoAg[2] + C.tf.z};
+  C.fconst = {cold[CD_RHOAG] + C.tf.x, cold[CD_RHOAG + 1] + C.tf.y, cold[CD_RHOAG + 2] + C.tf.z};
 }
 
 // boundary conditions at the base (cosserat_ode.py:194): everything but n, m is prescribed
 template <typename T>
-__device__ __forceinline__ bool ms_base_bc(const RodConst<T>& Pc, int r, T& g) {
-  if (r < 3) { g = Pc.p0[r]; return true; }
-  if (r < 7) { g = Pc.h0[r - 3]; return true; }
-  if (r < 13) return false;
-  if (r < 16) { g = Pc.q0[r - 13]; return true; }
-  g = Pc.w0[r - 16];
+__device__ __forceinline__ bool ms_base_bc(const T* cold, int r, T& g) {
+  if (r >= 7 && r < 13) return false;
+  // row order p h | n m | q w; the table stores p0 h0 q0 w0 contiguously
+  g = cold[r < 7 ? r : r - 6];
   return true;
 }
 
@@ -409,6 +473,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   const size_t rod_elems = (size_t)N * KR_SLOTS;
   const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, false), N, false);
   const MsRole R = ms_role(lane, N);
+  ms_cold_fill<T>(Pc, L.cold, lane);
+  wave_sync();
 
   // history terms (knode.py:74-75)
   for (int j = lane; j < N; j += WAVE) {
@@ -423,13 +489,13 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
     T g = extrapolate<T>(A.pred_order, A.cur[off], A.prev[off], A.prev2 ? A.prev2[off] : T(0));
     if (i == 0) {
       T bc;
-      if (ms_base_bc(Pc, r, bc)) g = bc;
+      if (ms_base_bc(L.cold, r, bc)) g = bc;
       else if (A.pred_order <= 0) g = A.G[rod * 6 + (r - 7)];  // caller's guess unless extrapolated
     }
     L.Xs[i * MS_YP + r] = g;
   }
   SweepCtx<T, HS> C;
-  ms_ctx_init<T, HS>(Pc, L.hist, A.tens + rod * A.tens_stride, C);
+  ms_ctx_init<T, HS>(L.cold, L.hist, A.tens + rod * A.tens_stride, C);
   MsSolveArgs<T> S;
   {  // z of the last grid point is never touched by a sweep
     const T* cl = A.cur + rod * rod_elems + (size_t)(N - 1) * KR_SLOTS;
@@ -467,6 +533,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, true), N, true);
   T* Yh = L.c12 + (size_t)N * 12;  // [3][P][MS_YP] interval-start states of the last three time levels
   const MsRole R = ms_role(lane, N);
+  ms_cold_fill<T>(Pc, L.cold, lane);
+  wave_sync();
 
   // leading slots (q w v u) of the newest state live in LDS (c12), those of the state before it in
   // registers (regP), both indexed lane-per-grid-point: the BDF2 history of the next step never
@@ -526,7 +594,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
       if (j < N) {
         T cv[12];
         load_hist_vec<T, 12>(L.c12 + (size_t)j * 12, cv);
-        build_hist_regs<T, HS>(Pc, A.hc1, A.hc2, cv, regP[q], L.hist + (size_t)j * HS);
+        build_hist_cold<T, HS>(L.cold, A.hc1, A.hc2, cv, regP[q], L.hist + (size_t)j * HS);
 #pragma unroll
         for (int c = 0; c < 12; ++c) regP[q][c] = cv[c];
       }
@@ -539,14 +607,14 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
                            Yh[(2 * MS_P + i) * MS_YP + r]);
       if (i == 0) {
         T bc;
-        if (ms_base_bc(Pc, r, bc)) g = bc;
+        if (ms_base_bc(L.cold, r, bc)) g = bc;
       }
       L.Xs[i * MS_YP + r] = g;
     }
     wave_sync();
     if (order <= 0 && lane < 6) L.Xs[0 * MS_YP + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
     SweepCtx<T, HS> C;
-    ms_ctx_init<T, HS>(Pc, L.hist, tens, C);
+    ms_ctx_init<T, HS>(L.cold, L.hist, tens, C);
     if (t + 1 < A.T_steps) {  // next step's tensions: issued now, consumed after this step's solve
 #pragma unroll
       for (int k = 0; k < 4; ++k) tens[k] = ctl[(t + 1) * 4 + k];

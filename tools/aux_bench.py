@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): throughput of the kernels that are not on the bench.py headline:
+batched ODE (K1), KNODE training epoch (K3/K4) at the BASELINE cfg3 / cfg4 shapes, forward sim with the MLP on."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "knode-cosserat_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import torch.nn as nn
+import cosserat_oracle as orc, krod_native as kn
+from cosserat_ode import CosseratRod
+from cosserat_ode_torch import CosseratRodTorch
+from knode import setup_robot, simulate_batch
+from krod_train import KnodeTrainer
+dev = "cuda:0"
+what = sys.argv[1:] or ["ode", "train", "simnn"]
+
+def timeit(fn, reps=5, inner=3):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(inner): fn()
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / inner)
+    return best
+
+if "ode" in what:
+    r = CosseratRod(); setup_robot(r); h = r._native()
+    for dt, es in ((torch.float32, 4), (torch.float64, 8)):
+        for Q in (1 << 16, 1 << 20, 1 << 22):
+            y = torch.randn(Q, 19, device=dev, dtype=dt); y[:, 3] += 3
+            yh = torch.randn(Q, 19, device=dev, dtype=dt); zh = torch.randn(Q, 6, device=dev, dtype=dt); tf = torch.randn(Q, 3, device=dev, dtype=dt)
+            t = timeit(lambda: h.ode_batch(y, yh, zh, tf))
+            print(f"ode_batch {str(dt):14s} Q={Q:8d}: {t*1e6:8.1f} us  {Q*78*es/t/1e9:7.1f} GB/s algorithmic  ({Q/t/1e6:.0f} M rows/s)")
+
+if "train" in what:
+    for name, M, T, N, kp, layers in (("cfg3 B=1024 N=100 T=64 [64,64]", 1024, 64, 100, [22, 67, 99], [64, 64]),
+                                      ("cfg4 shard 512 traj N=10 T=30 [512]", 512, 30, 10, [3, 5, 7, 9], [512]),
+                                      ("cfg4 shard 512 traj N=100 T=30 [512]", 512, 30, 100, [33, 55, 77, 99], [512]),
+                                      ("reference fast path 1 traj N=10 T=30 [512]", 1, 30, 10, [3, 5, 7, 9], [512])):
+        r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
+        ctl = orc.batch_sine_controls(M, T, r.del_t, 1236)
+        out = simulate_batch(r, ctl, dtype="f32")
+        traj = torch.as_tensor(out["traj"][:, :T], device=dev).float().contiguous()
+        controls = torch.as_tensor(ctl, device=dev).float().contiguous()
+        rob = CosseratRodTorch(dev, layers[0]); setup_robot(rob, "damping"); rob.N = N; rob.compute_intermediate_terms()
+        if len(layers) == 2:
+            mods = [nn.Linear(28, layers[0]), nn.ELU(), nn.Linear(layers[0], layers[1]), nn.ELU(), nn.Linear(layers[1], 25)]
+            for m in mods:
+                if isinstance(m, nn.Linear):
+                    rob.non_negative_normal_init(m, 0.01, 0.01); nn.init.normal_(m.bias, 0.0, 0.01)
+            rob.nn_models = nn.ModuleList(mods).to(dev)
+        tr = KnodeTrainer(rob, traj, controls, kp)
+        t_fb = timeit(lambda: tr.loss_and_grads(), reps=5, inner=5)
+        t_ep = timeit(lambda: tr.step(sync_loss=False), reps=5, inner=5)
+        dims = [28] + layers + [25]
+        flops = 6 * tr.Q * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        print(f"train {name}: Q={tr.Q} rows; fwd+loss+bwd {t_fb*1e6:8.1f} us ({flops/t_fb/1e12:.2f} TFLOP/s fp32), full epoch (+Adam+clamp) {t_ep*1e6:8.1f} us "
+              f"-> {M*(T-1)/t_ep/1e6:.2f} M trajectory-steps/s")
+
+if "simnn" in what:
+    for N, B, sizes in ((100, 1024, [28, 64, 64, 25]), (100, 1024, [28, 64, 25]), (10, 1024, [28, 512, 25])):
+        r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
+        mlp = orc.make_mlp(sizes, "elu", seed=7)
+        names = {orc.ACT_ELU: "ELU(alpha=1.0)"}
+        model, params = [], []
+        for W, b, a in zip(mlp.weights, mlp.biases, mlp.acts):
+            model.append("Linear"); params += [W, b]
+            if a != orc.ACT_NONE: model.append(names[a])
+        r.nn_model, r.param_ls, r.nn_path = model, params, "x"
+        h = r._native()
+        T = 6
+        ctl = torch.as_tensor(orc.batch_sine_controls(B, T + 3, r.del_t, 1235), device=dev).contiguous()
+        for dt in (torch.float64, torch.float32):
+            c = ctl.to(dt).contiguous()
+            st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
+            status = torch.zeros((B, T), dtype=torch.int32, device=dev)
+            h.simulate(c[:, :3].contiguous(), st, G, ring=True, use_nn=True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            h.simulate(c[:, 3:].contiguous(), st, G, ring=True, use_nn=True, status=status, prev_init=st[2])
+            torch.cuda.synchronize(); el = time.perf_counter() - t0
+            print(f"simulate NN on {sizes} N={N} B={B} {str(dt):14s}: {el/T*1e3:8.3f} ms/step -> {B*T/el/1e3:8.1f} k rod-steps/s bad={int((status!=0).sum())}")
