@@ -286,6 +286,7 @@ int kr_create(const kr_params* p, int device, kr_handle** out) {
   if (const char* e = std::getenv("KR_MS_MODE")) h->ms_mode = std::atoi(e);
   if (const char* e = std::getenv("KR_PREDICTOR")) h->predictor = std::atoi(e);
   if (const char* e = std::getenv("KR_PERSISTENT")) h->persistent = std::atoi(e) ? 1 : 0;
+  if (const char* e = std::getenv("KR_MFMA_MLP")) h->mfma_mlp = std::atoi(e) ? 1 : 0;
   *out = h;
   return KR_OK;
 }
@@ -302,6 +303,8 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
     h->ms_batch_limit = value;
   } else if (n == "persistent") {
     h->persistent = value ? 1 : 0;
+  } else if (n == "mfma_mlp") {
+    h->mfma_mlp = value ? 1 : 0;  // takes effect at the next kr_set_mlp
   } else if (n == "predictor") {
     if (value < 0 || value > 2) { set_error("predictor must be 0, 1 or 2"); return KR_E_ARG; }
     h->predictor = value;
@@ -320,6 +323,7 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   if (n == "ms_mode") *value = h->ms_mode;
   else if (n == "ms_batch_limit") *value = h->ms_batch_limit;
   else if (n == "persistent") *value = h->persistent;
+  else if (n == "mfma_mlp") *value = h->mfma_mlp;
   else if (n == "predictor") *value = h->predictor;
   else if (n == "last_sim_path") *value = h->last_sim_path;
   else {
@@ -430,6 +434,63 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
     md.Wt[k] = static_cast<double*>(dwd); md.b[k] = static_cast<double*>(dbd);
   }
   mf.max_dim = md.max_dim = maxd;
+  // ---- matrix-core form (mlp_mfma.hpp) --------------------------------------------------------
+  const bool shape_ok = (n_layers == 2 || n_layers == 3) && dims[0] == 28 && (n_layers == 2 || dims[1] <= 64) &&
+                        (n_layers == 2 || acts[0] == acts[1]) && acts[n_layers - 1] == KR_ACT_NONE;
+  mf.mfma_ok = md.mfma_ok = 0;
+  if (shape_ok) {
+    int prev_tiles = 0;
+    for (int k = 0; k < n_layers; ++k) {
+      const int in = dims[k], out = dims[k + 1];
+      const bool last = (k == n_layers - 1);
+      const int tiles = last ? 2 : ((out + 63) / 64) * 4;
+      const int ks = k == 0 ? 7 : prev_tiles * 4;
+      std::vector<float> hw((size_t)in * out), hb(out);
+      if (src_on_device) {
+        KR_HIP(hipMemcpy(hw.data(), W[k], hw.size() * sizeof(float), hipMemcpyDeviceToHost));
+        KR_HIP(hipMemcpy(hb.data(), b[k], hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+      } else {
+        std::memcpy(hw.data(), W[k], hw.size() * sizeof(float));
+        std::memcpy(hb.data(), b[k], hb.size() * sizeof(float));
+      }
+      std::vector<float> wf_f((size_t)tiles * ks * 64), bf_f((size_t)tiles * 4 * 64);
+      std::vector<double> wf_d(wf_f.size()), bf_d(bf_f.size());
+      for (int t = 0; t < tiles; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int uo = 16 * t + (lane & 15), q = lane >> 4;
+          for (int s2 = 0; s2 < ks; ++s2) {
+            // input unit of k-step s2 for lane group q: natural order for the first layer and for f64;
+            // for f32 the accumulator layout of the previous layer permutes it (mlp_mfma.hpp)
+            const int ui_d = 4 * s2 + q;
+            const int ui_f = k == 0 ? 4 * s2 + q : 16 * (s2 / 4) + 4 * q + (s2 % 4);
+            const size_t o = ((size_t)t * ks + s2) * 64 + lane;
+            wf_d[o] = (uo < out && ui_d < in) ? (double)hw[(size_t)uo * in + ui_d] : 0.0;
+            wf_f[o] = (uo < out && ui_f < in) ? hw[(size_t)uo * in + ui_f] : 0.f;
+          }
+          for (int r = 0; r < 4; ++r) {
+            const int row_d = 16 * t + q + 4 * r, row_f = 16 * t + 4 * q + r;
+            const size_t o = ((size_t)t * 4 + r) * 64 + lane;
+            bf_d[o] = row_d < out ? (double)hb[row_d] : 0.0;
+            bf_f[o] = row_f < out ? hb[row_f] : 0.f;
+          }
+        }
+      void *pwf, *pbf, *pwd, *pbd;
+      KR_HIP(hipMalloc(&pwf, wf_f.size() * sizeof(float)));  h->mlp_allocs.push_back(pwf);
+      KR_HIP(hipMalloc(&pbf, bf_f.size() * sizeof(float)));  h->mlp_allocs.push_back(pbf);
+      KR_HIP(hipMalloc(&pwd, wf_d.size() * sizeof(double))); h->mlp_allocs.push_back(pwd);
+      KR_HIP(hipMalloc(&pbd, bf_d.size() * sizeof(double))); h->mlp_allocs.push_back(pbd);
+      KR_HIP(hipMemcpy(pwf, wf_f.data(), wf_f.size() * sizeof(float), hipMemcpyHostToDevice));
+      KR_HIP(hipMemcpy(pbf, bf_f.data(), bf_f.size() * sizeof(float), hipMemcpyHostToDevice));
+      KR_HIP(hipMemcpy(pwd, wf_d.data(), wf_d.size() * sizeof(double), hipMemcpyHostToDevice));
+      KR_HIP(hipMemcpy(pbd, bf_d.data(), bf_d.size() * sizeof(double), hipMemcpyHostToDevice));
+      mf.wfrag[k] = static_cast<float*>(pwf);  mf.bfrag[k] = static_cast<float*>(pbf);
+      md.wfrag[k] = static_cast<double*>(pwd); md.bfrag[k] = static_cast<double*>(pbd);
+      mf.ksteps[k] = md.ksteps[k] = ks;
+      mf.otiles[k] = md.otiles[k] = tiles;
+      prev_tiles = tiles;
+    }
+    mf.mfma_ok = md.mfma_ok = h->mfma_mlp ? 1 : 0;
+  }
   h->mlp_f = mf;
   h->mlp_d = md;
   return KR_OK;

@@ -32,6 +32,12 @@ struct MlpDev {
   const T* Wt[KR_MAX_LAYERS];
   const T* b[KR_MAX_LAYERS];
   int max_dim;  // widest activation vector (incl. input and output)
+  // matrix-core form (mlp_mfma.hpp): weights / biases pre-packed in MFMA fragment order
+  const T* wfrag[KR_MAX_LAYERS];
+  const T* bfrag[KR_MAX_LAYERS];
+  int ksteps[KR_MAX_LAYERS];   // k-steps (of 4 inputs) per output tile
+  int otiles[KR_MAX_LAYERS];   // 16-unit output tiles (hidden layers: a multiple of 4)
+  int mfma_ok;                 // the network has a shape the matrix-core evaluator supports
 };
 
 }  // namespace kr
@@ -56,6 +62,7 @@ struct kr_handle {
   int last_sim_path = 0;     // what the last kr_simulate_batch did: 0 one single-shooting launch per step,
                              // 1 one multiple-shooting launch per step, 2 one persistent launch for all steps
   void* dbg = nullptr;       // diagnostic cycle-counter buffer (kr_debug_buffer)
+  int mfma_mlp = 1;          // evaluate the in-sweep MLP on the matrix cores when its shape allows
   int persistent = 1;        // kr_simulate_batch: run all steps in one launch when the multiple-shooting kernel applies
 };
 

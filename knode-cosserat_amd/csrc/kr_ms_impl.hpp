@@ -55,8 +55,12 @@ enum : int {
 };
 // LDS elements of one rod (a multiple of 4, so every rod's slice stays 16-byte aligned)
 template <typename T, int HS>
-__host__ __device__ inline size_t ms_lds_elems(int N, bool persist) {
-  size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + (MS_YP + 1) * 8 + 48 + CD_SIZE + WAVE + ((WAVE * MS_YP + 3) & ~3);
+__host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = false) {
+  // XB, Tm, IH, Es are contiguous; with the MLP on the same region doubles as the 64 x 32 exchange
+  // tile of mlp_mfma.hpp.  The cold table sits in front of XB so the tile cannot clobber it.
+  size_t alg = (MS_YP + 1) * 8 + 48 + WAVE + ((WAVE * MS_YP + 3) & ~3);
+  if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
+  size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + alg;
   if (persist) n += (size_t)N * 12 + 3 * MS_P * MS_YP;
   return (n + 3) & ~size_t(3);
 }
@@ -172,10 +176,10 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist) {
   L.hist = smem;
   L.Xs = L.hist + (size_t)N * HS;
   // everything accessed with 16-byte vectors sits at a multiple of 4 elements
-  L.XB = L.Xs + ((MS_P * MS_YP + 3) & ~3);
+  L.cold = L.Xs + ((MS_P * MS_YP + 3) & ~3);
+  L.XB = L.cold + ((CD_SIZE + 3) & ~3);
   L.Tm = L.XB + (MS_YP + 1) * 8;
-  L.cold = L.Tm + 48;
-  L.IH = L.cold + CD_SIZE;
+  L.IH = L.Tm + 48;
   L.Es = L.IH + WAVE;
   L.c12 = persist ? L.Es + ((WAVE * MS_YP + 3) & ~3) : nullptr;
   return L;
@@ -193,15 +197,15 @@ struct MsSolveArgs {
 // Newton iteration on (G, Y_1..Y_{P-1}) for one rod = one wavefront.  On entry L.hist holds the
 // history records and L.Xs the initial guess (visible to all lanes).  Returns the status; `it`
 // = sweeps used.  On exit L.Xs holds the accepted unknowns.
-template <typename T, bool DIAG, int SCHEME, int HS, bool PERSIST>
-__device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MsLds<T>& L, const MsRole& R, int lane,
-                                         const SweepCtx<T, HS>& C, const MsSolveArgs<T>& S, int& it, MsStamps& stamps) {
+template <typename T, bool DIAG, int SCHEME, int HS, bool PERSIST, bool NN>
+__device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>& M, const MsLds<T>& L, const MsRole& R,
+                                         int lane, const SweepCtx<T, HS>& C, const MsSolveArgs<T>& S, int& it,
+                                         MsStamps& stamps) {
   const int N = Pc.N;
 #ifdef KR_MS_STAMPS
   unsigned long long tq;
   KR_STAMP(tq);
 #endif
-  const MlpDev<T> Mdummy{};
   T* Xs = L.Xs; T* Es = L.Es; T* IH = L.IH; T* XB = L.XB; T* Tm = L.Tm;
   const int iv = R.iv, col = R.col;
   const bool idle = R.idle;
@@ -230,12 +234,16 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MsLds<T>& 
     T hv[HS];
     load_hist_vec<T, HS>(C.hbase + (size_t)R.s_i * HS, hv);
     for (int t = 0; t < R.lmax; ++t) {
-      if (t < R.len_i) {
-        const int j = R.s_i + t;
+      // with the MLP on every lane must reach the wave-wide matrix-core call: lanes past the end of
+      // their (shorter) interval keep running on the last grid point and simply do not commit
+      const bool live = t < R.len_i;
+      if (NN || live) {
+        const int j = live ? R.s_i + t : R.s_i + R.len_i - 1;
+        const RodState<T> y_in = y;
         RodState<T> k1;
         V3<T> v, u;
-        eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, y, hv, k1, v, u);
-        if (st) {
+        eval_point<T, DIAG, NN, HS>(Pc, M, C, y, hv, k1, v, u);
+        if (st && live) {
           T rec[KR_SLOTS];
           record_from(y, v, u, rec);
           if (S.out_rod) store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
@@ -257,17 +265,20 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MsLds<T>& 
           RodState<T> k2, k3, k4;
           V3<T> v2, u2;
           RodState<T> ya = state_axpy(y, Pc.ds * T(0.5), k1);
-          eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, ya, hm, k2, v2, u2);
+          eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k2, v2, u2);
           ya = state_axpy(y, Pc.ds * T(0.5), k2);
-          eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, ya, hm, k3, v2, u2);
+          eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k3, v2, u2);
           ya = state_axpy(y, Pc.ds, k3);
-          eval_point<T, DIAG, false, HS>(Pc, Mdummy, C, ya, hn, k4, v2, u2);
+          eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hn, k4, v2, u2);
           RodState<T> ksum = state_axpy(k1, T(2), k2);
           ksum = state_axpy(ksum, T(2), k3);
           ksum = state_axpy(ksum, T(1), k4);
           y = state_axpy(y, Pc.ds / T(6), ksum);
 #pragma unroll
           for (int c = 0; c < HS; ++c) hv[c] = hn[c];
+        }
+        if constexpr (NN) {
+          if (!live) y = y_in;
         }
       }
     }
@@ -439,6 +450,7 @@ template <typename T, int HS>
 __device__ __forceinline__ void ms_ctx_init(const T* cold, const T* hist, const T* tens4, SweepCtx<T, HS>& C) {
   C.hbase = hist;
   C.bufA = nullptr; C.bufB = nullptr; C.astride = 0;
+  C.tile = nullptr; C.lane = 0;
   C.tf = {T(0), T(0), T(0)};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {  // cosserat_ode.py:195
@@ -462,8 +474,9 @@ __device__ __forceinline__ bool ms_base_bc(const T* cold, int r, T& g) {
 // ---------------------------------------------------------------------------
 // one time step per launch (kr_step_batch, and kr_simulate_batch when the persistent form does not apply)
 // ---------------------------------------------------------------------------
-template <typename T, bool DIAG, int SCHEME, int HS>
-__global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T> Pc, const StepArgs<T> A) {
+template <typename T, bool DIAG, int SCHEME, int HS, bool NN>
+__global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T> Pc, const StepArgs<T> A,
+                                                                const MlpDev<T> M) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = Pc.N;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   const int64_t rod = (int64_t)blockIdx.x * MS_WPB + wv;
   if (rod >= A.B) return;  // whole wavefront; there is no workgroup barrier in this kernel
   const size_t rod_elems = (size_t)N * KR_SLOTS;
-  const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, false), N, false);
+  const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, false, NN), N, false);
   const MsRole R = ms_role(lane, N);
   ms_cold_fill<T>(Pc, L.cold, lane);
   wave_sync();
@@ -496,6 +509,12 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   }
   SweepCtx<T, HS> C;
   ms_ctx_init<T, HS>(L.cold, L.hist, A.tens + rod * A.tens_stride, C);
+  if constexpr (NN) {
+    // exchange tile of the matrix-core MLP: used during sweeps only, so it lives on top of the
+    // condensation buffers (XB .. Es), which are used between sweeps only
+    C.tile = L.XB;
+    C.lane = lane;
+  }
   MsSolveArgs<T> S;
   {  // z of the last grid point is never touched by a sweep
     const T* cl = A.cur + rod * rod_elems + (size_t)(N - 1) * KR_SLOTS;
@@ -508,7 +527,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   wave_sync();
   int it;
   MsStamps stamps;
-  const int status = ms_newton<T, DIAG, SCHEME, HS, false>(Pc, L, R, lane, C, S, it, stamps);
+  const int status = ms_newton<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it, stamps);
   if (lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * MS_YP + 7 + lane];
   if (lane == 0) {
     if (A.status) A.status[rod * A.st_stride] = status;
@@ -627,7 +646,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     KR_STAMP_ADD(stamps.prep, tp);
 #endif
     int it;
-    const int status = ms_newton<T, DIAG, SCHEME, HS, true>(Pc, L, R, lane, C, S, it, stamps);
+    const int status = ms_newton<T, DIAG, SCHEME, HS, true, false>(Pc, MlpDev<T>{}, L, R, lane, C, S, it, stamps);
     if (lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
     // ---- shift the time levels of the unknowns ------------------------------------
     for (int e = lane; e < MS_P * 19; e += WAVE) {
@@ -654,21 +673,21 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
 }
 
 template <typename T, int HS>
-static size_t ms_lds_bytes(int N, bool persist = false) {
-  return sizeof(T) * ms_lds_elems<T, HS>(N, persist) * MS_WPB;
+static size_t ms_lds_bytes(int N, bool persist = false, bool nn = false) {
+  return sizeof(T) * ms_lds_elems<T, HS>(N, persist, nn) * MS_WPB;
 }
 
-template <typename T, bool DIAG, int SCHEME>
-static int launch_ms_inst(const RodConst<T>& P, const StepArgs<T>& a, hipStream_t s) {
-  auto kern = ms_step_kernel<T, DIAG, SCHEME, hs_phys<T>()>;
-  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N);
+template <typename T, bool DIAG, int SCHEME, bool NN>
+static int launch_ms_inst(const RodConst<T>& P, const MlpDev<T>& M, const StepArgs<T>& a, hipStream_t s) {
+  auto kern = ms_step_kernel<T, DIAG, SCHEME, hs_phys<T>(), NN>;
+  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, false, NN);
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
     configured = smem;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a, M);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }
@@ -677,26 +696,34 @@ static int launch_ms_inst(const RodConst<T>& P, const StepArgs<T>& a, hipStream_
 template <typename T>
 static bool ms_eligible(kr_handle* h, int use_nn, const StepArgs<T>& a) {
   const RodConst<T>& P = consts<T>(h);
-  if (use_nn || a.mode != 0) return false;
+  if (a.mode != 0) return false;
+  if (use_nn) {  // the MLP must be one the matrix-core evaluator serves (no per-lane activation buffers here)
+    const MlpDev<T>& M = mlpdev<T>(h);
+    if (M.n_layers <= 0 || !M.mfma_ok || h->params.nn_input_history) return false;
+  }
   if (h->ms_mode == 0) return false;
   if (P.N - 1 < 2 * MS_P) return false;                 // too few segments to cut
-  if (ms_lds_bytes<T, hs_phys<T>()>(P.N) > (size_t)h->lds_limit) return false;
+  if (ms_lds_bytes<T, hs_phys<T>()>(P.N, false, use_nn != 0) > (size_t)h->lds_limit) return false;
   if (h->ms_mode == 1) return true;                     // forced
   return a.B <= (int64_t)h->ms_batch_limit;             // auto: latency mode for small batches
 }
 
-template <typename T>
-static int launch_ms(kr_handle* h, int scheme, const StepArgs<T>& a, hipStream_t s) {
+template <typename T, bool NN>
+static int launch_ms_nn(kr_handle* h, int scheme, const StepArgs<T>& a, hipStream_t s) {
   const RodConst<T>& P = consts<T>(h);
-  h->last_sim_path = 1;
+  const MlpDev<T>& M = mlpdev<T>(h);
   if (scheme == KR_EULER)
-    return P.diag ? launch_ms_inst<T, true, KR_EULER>(P, a, s) : launch_ms_inst<T, false, KR_EULER>(P, a, s);
+    return P.diag ? launch_ms_inst<T, true, KR_EULER, NN>(P, M, a, s) : launch_ms_inst<T, false, KR_EULER, NN>(P, M, a, s);
   if (scheme == KR_RK4)
-    return P.diag ? launch_ms_inst<T, true, KR_RK4>(P, a, s) : launch_ms_inst<T, false, KR_RK4>(P, a, s);
+    return P.diag ? launch_ms_inst<T, true, KR_RK4, NN>(P, M, a, s) : launch_ms_inst<T, false, KR_RK4, NN>(P, M, a, s);
   set_error("unknown scheme");
   return KR_E_ARG;
 }
-
+template <typename T>
+static int launch_ms(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s) {
+  h->last_sim_path = 1;
+  return use_nn ? launch_ms_nn<T, true>(h, scheme, a, s) : launch_ms_nn<T, false>(h, scheme, a, s);
+}
 template <typename T, bool DIAG, int SCHEME>
 static int launch_ms_sim_inst(const RodConst<T>& P, const SimArgs<T>& a, hipStream_t s) {
   auto kern = ms_sim_kernel<T, DIAG, SCHEME, hs_phys<T>()>;

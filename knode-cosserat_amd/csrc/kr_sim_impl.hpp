@@ -23,6 +23,7 @@
 #pragma once
 #include "kr_internal.hpp"
 #include "mlp_lane.hpp"
+#include "mlp_mfma.hpp"
 
 namespace kr {
 
@@ -221,10 +222,30 @@ __device__ __forceinline__ void solve6(T (&a)[6][7], T (&x)[6]) {
 // MLP correction inside a sweep (cosserat_ode.py:169-184)
 // ---------------------------------------------------------------------------
 template <typename T, int HS>
-__device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB, int stride, const RodState<T>& y,
-                                           const T (&hv)[HS], V3<T> tf, RodState<T>& ys, V3<T>& v, V3<T>& u) {
+__device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB, int stride, T* tile, int lane,
+                                           const RodState<T>& y, const T (&hv)[HS], V3<T> tf, RodState<T>& ys, V3<T>& v,
+                                           V3<T>& u) {
   T yr[19];
   state_to_rows(y, yr);
+  if constexpr (HS != HS_NNH) {
+    if (M.mfma_ok) {  // wave-uniform: the 64 evaluations of the wave as GEMMs on the matrix cores
+      T x[MM_IN];
+#pragma unroll
+      for (int i = 0; i < 19; ++i) x[i] = yr[i];
+      x[19] = v.x; x[20] = v.y; x[21] = v.z; x[22] = u.x; x[23] = u.y; x[24] = u.z;
+      x[25] = tf.x; x[26] = tf.y; x[27] = tf.z;
+      T d[25];
+      mlp_mfma_eval<T>(M, x, tile, lane, d);
+      T yr2[19];
+      state_to_rows(ys, yr2);
+#pragma unroll
+      for (int i = 0; i < 19; ++i) yr2[i] += d[i];
+      ys = rows_to_state(yr2);
+      v = {v.x + d[19], v.y + d[20], v.z + d[21]};
+      u = {u.x + d[22], u.y + d[23], u.z + d[24]};
+      return;
+    }
+  }
   int o = 0;
 #pragma unroll
   for (int i = 0; i < 19; ++i) bufA[(o + i) * stride] = yr[i];
@@ -265,9 +286,11 @@ __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB,
 template <typename T, int HS>
 struct SweepCtx {
   const T* hbase;   // history of this lane's rod: [N][HS], LDS or global
-  T* bufA;          // MLP activation columns of this lane
+  T* bufA;          // MLP activation columns of this lane (per-lane evaluator)
   T* bufB;
   int astride;
+  T* tile;          // LDS exchange tile of the wave (matrix-core evaluator)
+  int lane;
   V3<T> tf, fconst;
 };
 
@@ -277,7 +300,7 @@ __device__ __forceinline__ void eval_point(const RodConst<T>& P, const MlpDev<T>
                                            const RodState<T>& y, const T (&hv)[HS], RodState<T>& k, V3<T>& v,
                                            V3<T>& u) {
   ode_eval<T, DIAG>(P, y, hist_from<T, HS>(hv), C.fconst, k, v, u);
-  if constexpr (NN) nn_correct<T, HS>(M, C.bufA, C.bufB, C.astride, y, hv, C.tf, k, v, u);
+  if constexpr (NN) nn_correct<T, HS>(M, C.bufA, C.bufB, C.astride, C.tile, C.lane, y, hv, C.tf, k, v, u);
 }
 
 template <typename T, bool DIAG, int SCHEME, bool HIST_LDS, bool NN, int HS>
@@ -315,8 +338,12 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
   C.bufA = nullptr;
   C.bufB = nullptr;
   C.astride = 0;
+  C.tile = nullptr;
+  C.lane = lane;
   if constexpr (NN) {
-    if (A.act_ws == nullptr) {
+    if (M.mfma_ok && HS != HS_NNH) {
+      C.tile = smem + (HIST_LDS ? (size_t)RPW * N * HS : 0);
+    } else if (A.act_ws == nullptr) {
       T* a0 = smem + (HIST_LDS ? (size_t)RPW * N * HS : 0);
       C.bufA = a0 + lane;
       C.bufB = a0 + (size_t)M.max_dim * WAVE + lane;
@@ -559,7 +586,8 @@ static int launch_step_mem(kr_handle* h, StepArgs<T> a, hipStream_t s) {
   const int N = P.N;
   const int grid = (int)((a.B + RPW - 1) / RPW);
   const size_t hist_lds = (size_t)RPW * N * HS * sizeof(T);
-  const size_t act_lds = NN ? (size_t)2 * M.max_dim * WAVE * sizeof(T) : 0;
+  const bool mfma = NN && M.mfma_ok && HS != HS_NNH;
+  const size_t act_lds = !NN ? 0 : mfma ? (size_t)WAVE * MM_TILE_LD * sizeof(T) : (size_t)2 * M.max_dim * WAVE * sizeof(T);
   const size_t limit = (size_t)h->lds_limit;
   bool hist_in_lds = hist_lds <= limit;
   bool act_in_lds = NN && (act_lds + (hist_in_lds ? hist_lds : 0) <= limit);
@@ -610,11 +638,11 @@ static int launch_step_nn(kr_handle* h, int use_nn, const StepArgs<T>& a, hipStr
 template <typename T>
 static bool ms_eligible(kr_handle* h, int use_nn, const StepArgs<T>& a);
 template <typename T>
-static int launch_ms(kr_handle* h, int scheme, const StepArgs<T>& a, hipStream_t s);
+static int launch_ms(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s);
 
 template <typename T>
 int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s) {
-  if (ms_eligible<T>(h, use_nn, a)) return launch_ms<T>(h, scheme, a, s);
+  if (ms_eligible<T>(h, use_nn, a)) return launch_ms<T>(h, scheme, use_nn, a, s);
   if (scheme == KR_EULER) return launch_step_nn<T, KR_EULER>(h, use_nn, a, s);
   if (scheme == KR_RK4) return launch_step_nn<T, KR_RK4>(h, use_nn, a, s);
   set_error("unknown scheme");

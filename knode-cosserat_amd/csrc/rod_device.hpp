@@ -211,25 +211,130 @@ __device__ __forceinline__ RodState<T> state_axpy(const RodState<T>& y, T a, con
   return r;
 }
 
+// exp(x) for the activations: one rounding-level-accurate, short instruction sequence instead of the
+// library routine (the MLP evaluates 128 activations per lane per call, so ocml's ~100-instruction
+// fp64 expm1/tanh dominated the matrix-core evaluator).  x = k ln2 + r, |r| <= ln2/2, Taylor to
+// degree 13 (remainder 2e-16), scaled by 2^k with v_ldexp.
+__device__ __forceinline__ double fast_exp(double x) {
+  x = fmin(fmax(x, -745.0), 709.0);
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)k);
+}
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }  // v_exp_f32 on x*log2(e)
+
+// Block form: the same arithmetic on N independent values with the loops ordered coefficient-major,
+// so that the dependent FMA chain of one value (9.5 cycles per fp64 op) is interleaved with the
+// chains of the others instead of being executed back to back.
+template <int N>
+__device__ __forceinline__ void fast_exp_block(const double (&xin)[N], double (&y)[N]) {
+  double k[N], r[N], p[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const double x = fmin(fmax(xin[e], -745.0), 709.0);
+    k[e] = __builtin_rint(x * 1.4426950408889634);
+    r[e] = fma(-k[e], 6.93147180369123816490e-01, x);
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    r[e] = fma(-k[e], 1.90821492927058770002e-10, r[e]);
+    p[e] = 1.0 / 6227020800.0;
+  }
+  constexpr double c[13] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                            1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+#pragma unroll
+  for (int j = 0; j < 13; ++j)
+#pragma unroll
+    for (int e = 0; e < N; ++e) p[e] = fma(p[e], r[e], c[j]);
+#pragma unroll
+  for (int e = 0; e < N; ++e) y[e] = __builtin_ldexp(p[e], (int)k[e]);
+}
+template <int N>
+__device__ __forceinline__ void fast_exp_block(const float (&xin)[N], float (&y)[N]) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) y[e] = __expf(xin[e]);
+}
+
+// exp(x) - 1 for x <= 0.  fp64: literally the reference's np.exp(x) - 1 (cosserat_ode.py:94);
+// fp32: torch's ELU uses expm1, so keep relative accuracy for small |x| with a short series.
+__device__ __forceinline__ double elu_neg(double x) { return fast_exp(x) - 1.0; }
+__device__ __forceinline__ float elu_neg(float x) {
+  const float series = x * (1.f + x * (0.5f + x * (0.16666667f + x * (0.041666668f + x * 0.0083333338f))));
+  return x > -0.25f ? series : __expf(x) - 1.f;
+}
+
 // activation functions of the residual MLP, cosserat_ode.py:92-106
 template <typename T>
 __device__ __forceinline__ T activate(int code, T x) {
   switch (code) {
-    case KR_ACT_TANH: return tanh(x);
-    case KR_ACT_SOFTPLUS: return log1p(exp(-fabs(x))) + fmax(x, T(0));
+    case KR_ACT_TANH: {  // 1 - 2/(e^{2x}+1): absolute error at rounding level, no cancellation blow-up
+      const T e = fast_exp(T(2) * x);
+      return T(1) - T(2) * fast_rcp(e + T(1));
+    }
+    case KR_ACT_SOFTPLUS: return log1p(fast_exp(-fabs(x))) + fmax(x, T(0));
     case KR_ACT_RELU: return fmax(x, T(0));
-    case KR_ACT_ELU: return x > T(0) ? x : expm1(x);
+    case KR_ACT_ELU: {  // branch-free: both sides are cheap, one v_cndmask picks
+      const T e = elu_neg(fmin(x, T(0)));
+      return x > T(0) ? x : e;
+    }
     default: return x;
   }
 }
 template <typename T>
 __device__ __forceinline__ T activate_grad(int code, T pre) {  // d act / d pre
   switch (code) {
-    case KR_ACT_TANH: { T t = tanh(pre); return T(1) - t * t; }
-    case KR_ACT_SOFTPLUS: return T(1) / (T(1) + exp(-pre));
+    case KR_ACT_TANH: {
+      const T e = fast_exp(T(2) * pre);
+      const T t = T(1) - T(2) * fast_rcp(e + T(1));
+      return T(1) - t * t;
+    }
+    case KR_ACT_SOFTPLUS: return fast_rcp(T(1) + fast_exp(-pre));
     case KR_ACT_RELU: return pre > T(0) ? T(1) : T(0);
-    case KR_ACT_ELU: return pre > T(0) ? T(1) : exp(pre);
+    case KR_ACT_ELU: return pre > T(0) ? T(1) : fast_exp(pre);
     default: return T(1);
+  }
+}
+
+// activation of N independent values at once (see fast_exp_block); ACT is a compile-time code
+template <typename T, int ACT, int N>
+__device__ __forceinline__ void activate_block(T (&x)[N]) {
+  if constexpr (ACT == KR_ACT_ELU) {
+    T xm[N], ex[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) xm[e] = fmin(x[e], T(0));
+    if constexpr (sizeof(T) == 8) {
+      fast_exp_block<N>(xm, ex);
+#pragma unroll
+      for (int e = 0; e < N; ++e) x[e] = x[e] > T(0) ? x[e] : ex[e] - T(1);
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) x[e] = x[e] > T(0) ? x[e] : elu_neg(xm[e]);
+    }
+  } else if constexpr (ACT == KR_ACT_TANH) {
+    T t2[N], ex[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) t2[e] = T(2) * x[e];
+    fast_exp_block<N>(t2, ex);
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] = T(1) - T(2) * fast_rcp(ex[e] + T(1));
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] = activate<T>(ACT, x[e]);
   }
 }
 
