@@ -287,6 +287,7 @@ int kr_create(const kr_params* p, int device, kr_handle** out) {
   if (const char* e = std::getenv("KR_PREDICTOR")) h->predictor = std::atoi(e);
   if (const char* e = std::getenv("KR_PERSISTENT")) h->persistent = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_MFMA_MLP")) h->mfma_mlp = std::atoi(e) ? 1 : 0;
+  if (const char* e = std::getenv("KR_FUSED_MLP")) h->fused_mlp = std::atoi(e) ? 1 : 0;
   *out = h;
   return KR_OK;
 }
@@ -303,6 +304,8 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
     h->ms_batch_limit = value;
   } else if (n == "persistent") {
     h->persistent = value ? 1 : 0;
+  } else if (n == "fused_mlp") {
+    h->fused_mlp = value ? 1 : 0;
   } else if (n == "mfma_mlp") {
     h->mfma_mlp = value ? 1 : 0;  // takes effect at the next kr_set_mlp
   } else if (n == "predictor") {
@@ -324,6 +327,7 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   else if (n == "ms_batch_limit") *value = h->ms_batch_limit;
   else if (n == "persistent") *value = h->persistent;
   else if (n == "mfma_mlp") *value = h->mfma_mlp;
+  else if (n == "fused_mlp") *value = h->fused_mlp;
   else if (n == "predictor") *value = h->predictor;
   else if (n == "last_sim_path") *value = h->last_sim_path;
   else {

@@ -62,6 +62,7 @@ struct kr_handle {
   int last_sim_path = 0;     // what the last kr_simulate_batch did: 0 one single-shooting launch per step,
                              // 1 one multiple-shooting launch per step, 2 one persistent launch for all steps
   void* dbg = nullptr;       // diagnostic cycle-counter buffer (kr_debug_buffer)
+  int fused_mlp = 1;         // training: fused MFMA forward/backward kernels (kr_mlp_fused.hip) when the shape allows
   int mfma_mlp = 1;          // evaluate the in-sweep MLP on the matrix cores when its shape allows
   int persistent = 1;        // kr_simulate_batch: run all steps in one launch when the multiple-shooting kernel applies
 };
@@ -142,6 +143,14 @@ struct SimArgs {
 // returns 1 when the persistent form does not apply
 template <typename T>
 int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>& a, hipStream_t s);
+
+// kr_mlp_fused.hip: fused fp32 MLP forward / backward for training
+bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad);
+size_t fused_ws_bytes(int n_layers, const int32_t* dims);
+int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
+                      const float* const* b, const float* x, float* out, void* ws, hipStream_t s);
+int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
+                       const float* x, const float* dout, void* ws, float* const* dW, float* const* db, hipStream_t s);
 
 // kr_ode.hip
 template <typename T>

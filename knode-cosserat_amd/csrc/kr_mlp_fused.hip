@@ -1,0 +1,531 @@
+// kr_mlp_fused.hip - fused fp32 forward / backward of the residual MLP for the KNODE training step
+// (reference: CosseratRodTorch.forward, cosserat_ode_torch.py:131-134, and loss.backward() of
+// physics_train.py:290,394 restricted to the MLP parameters).
+//
+// One wavefront owns blocks of 64 rows.  Everything is expressed in the transposed form
+// [units x samples] so that an MFMA accumulator tile (v_mfma_f32_16x16x4_f32: lane l holds column
+// sample l&15, rows 4*(l>>4)+r) is directly the B operand of the next product:
+//
+//   forward   Z1 = W1 X^T + b1, A1 = act(Z1);  Z2 = W2 A1 + b2, A2 = act(Z2);  OUT = W3 A2 + b3
+//   backward  dZ2 = (W3^T dOUT) * act'(Z2);  dZ1 = (W2^T dZ2) * act'(Z1)          (chain in registers)
+//             dW3 += dOUT A2^T, dW2 += dZ2 A1^T, dW1 += dZ1 X^T                   (contraction over the 64
+//             samples: both operands go through an LDS tile [sample][unit], the products accumulate in
+//             registers over all row blocks of the wave and are added to HBM once, with float atomics)
+//
+// The backward kernel recomputes the hidden activations instead of reading them back (the forward
+// kernel stores nothing but OUT), so a training step moves X, OUT and dOUT through HBM exactly once:
+// 3 x 128 B per row.  Weights are re-packed into MFMA fragment order on the device at every call
+// (they are torch parameters that change every optimizer step; ~30 KB).
+// Shapes served: in(<=32) -> H1 -> 25 with any H1 (streamed in chunks of 64 units) and
+// in -> H1 -> H2 -> 25 with H1, H2 <= 64; one activation for all hidden layers.  Other networks
+// use the generic GEMM path of kr_train.hip.
+#include <type_traits>
+
+#include "kr_internal.hpp"
+
+namespace kr {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int FT = 4;        // sample tiles per row block (64 rows)
+constexpr int FPD = 3;       // prefetch distance of weight fragments, in k-steps
+constexpr int F_LDX = 32;    // row length of the X / dOUT tiles
+constexpr int F_LDH = 64;    // row length of the hidden tiles
+
+struct FChunk {
+  f4 a[4][FT];  // [unit tile][sample tile]
+};
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void fsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- weight packing (device side, every call) ------------------------------------------------------
+// forward fragments: wf[(t*ks + s)*64 + lane] = W[16t + (lane&15)][unit_in(s, lane>>4)], bias fragments
+// bf[(t*4 + r)*64 + lane] = b[16t + 4*(lane>>4) + r]
+__global__ void pack_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b, int in, int out, int tiles,
+                                int ks, int first, float* __restrict__ wf, float* __restrict__ bf) {
+  const int n = tiles * ks * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, s = (i >> 6) % ks, t = (i >> 6) / ks;
+    const int uo = 16 * t + (lane & 15), q = lane >> 4;
+    const int ui = first ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
+    wf[i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
+  }
+  const int nb = tiles * 4 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, r = (i >> 6) & 3, t = i >> 8;
+    const int u = 16 * t + 4 * (lane >> 4) + r;
+    bf[i] = u < out ? b[u] : 0.f;
+  }
+}
+// transposed fragments for dA_prev = W^T dZ: wt[(ti*ks + s)*64 + lane] = W[unit_out(s, q)][16*ti + (lane&15)]
+__global__ void pack_bwd_kernel(const float* __restrict__ W, int in, int out, int in_tiles, int ks, int natural,
+                                float* __restrict__ wt) {
+  const int n = in_tiles * ks * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, s = (i >> 6) % ks, ti = (i >> 6) / ks;
+    const int ui = 16 * ti + (lane & 15), q = lane >> 4;
+    const int uo = natural ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
+    wt[i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
+  }
+}
+
+// ---- register-level building blocks ------------------------------------------------------------------
+// dst[o][s] += Wfrag[tile0+o][ks0+k] * bsrc(s, k), k < KS, weight fragments prefetched FPD k-steps ahead
+template <int NO, int KS, typename BFn>
+__device__ __forceinline__ void facc(f4 (&dst)[NO][FT], const float* __restrict__ w, int ksteps, int tile0, int ks0,
+                                     int lane, BFn bsrc) {
+  float a[KS][NO];
+#pragma unroll
+  for (int k = 0; k < (FPD < KS ? FPD : KS); ++k)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) a[k][o] = w[((size_t)(tile0 + o) * ksteps + ks0 + k) * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    if (k + FPD < KS) {
+#pragma unroll
+      for (int o = 0; o < NO; ++o) a[k + FPD][o] = w[((size_t)(tile0 + o) * ksteps + ks0 + k + FPD) * 64 + lane];
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int s = 0; s < FT; ++s) dst[o][s] = mfma4(a[k][o], bsrc(s, k), dst[o][s]);
+  }
+}
+__device__ __forceinline__ void chunk_set_bias(FChunk& h, const float* __restrict__ bf, int tile0, int lane) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    f4 b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = bf[((size_t)(tile0 + o) * 4 + r) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < FT; ++s) h.a[o][s] = b;
+  }
+}
+__device__ __forceinline__ void chunk_zero(FChunk& h) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s) h.a[o][s] = f4{0.f, 0.f, 0.f, 0.f};
+}
+// z -> act(z) in place, g = act'(z)
+template <int ACT>
+__device__ __forceinline__ void chunk_act_grad(FChunk& z, FChunk& g) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = z.a[o][s][r];
+        g.a[o][s][r] = activate_grad<float>(ACT, v);
+        z.a[o][s][r] = activate<float>(ACT, v);
+      }
+}
+template <int ACT>
+__device__ __forceinline__ void chunk_act_only(FChunk& z) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z.a[o][s][r] = activate<float>(ACT, z.a[o][s][r]);
+}
+__device__ __forceinline__ void chunk_mul(FChunk& d, const FChunk& g) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s) d.a[o][s] = d.a[o][s] * g.a[o][s];
+}
+// D layout -> LDS tile[sample][unit] (row length ld)
+__device__ __forceinline__ void chunk_to_tile(float* tile, int ld, const FChunk& h, int lane) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(16 * s + (lane & 15)) * ld + 16 * o + 4 * (lane >> 4) + r] = h.a[o][s][r];
+}
+// acc[o][i] += sum over the 64 samples of A[sample][16o + .] * B[sample][16i + .]  (both LDS tiles)
+template <int NO, int NI>
+__device__ __forceinline__ void wgrad(f4 (&acc)[NO][NI], const float* ta, int lda, const float* tb, int ldb, int lane) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int row = 4 * k + (lane >> 4);
+    float a[NO], b[NI];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) a[o] = ta[row * lda + 16 * o + (lane & 15)];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) b[i] = tb[row * ldb + 16 * i + (lane & 15)];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[o][i] = mfma4(a[o], b[i], acc[o][i]);
+  }
+}
+// accumulator tiles -> global dW[out][in] (nn.Linear layout) with float atomics
+template <int NO, int NI>
+__device__ __forceinline__ void wgrad_flush(const f4 (&acc)[NO][NI], float* __restrict__ dW, int out, int in, int out0,
+                                            int in0, int lane) {
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int uo = out0 + 16 * o + 4 * (lane >> 4) + r, ui = in0 + 16 * i + (lane & 15);
+        if (uo < out && ui < in) atomicAdd(&dW[(size_t)uo * in + ui], acc[o][i][r]);
+      }
+}
+// per-lane partial column sums of a D-layout chunk (sum over its sample tiles)
+__device__ __forceinline__ void bias_partial(f4 (&p)[4], const FChunk& d) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s) p[o] = p[o] + d.a[o][s];
+}
+__device__ __forceinline__ void bias_flush(const f4 (&p)[4], float* __restrict__ db, int out, int out0, int lane) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = p[o][r];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+      const int u = out0 + 16 * o + 4 * (lane >> 4) + r;
+      if ((lane & 15) == 0 && u < out) atomicAdd(&db[u], v);
+    }
+}
+
+// rows [row0, row0+64) of a row-major [Q][32] array -> LDS tile (zero beyond Q)
+__device__ __forceinline__ void stage_rows(const float* __restrict__ g, int64_t row0, int64_t Q, float* tile, int lane) {
+  const int64_t row = row0 + lane;
+  const f4* src = reinterpret_cast<const f4*>(g + row * F_LDX);
+  f4* dst = reinterpret_cast<f4*>(tile + lane * F_LDX);
+#pragma unroll
+  for (int c = 0; c < F_LDX / 4; ++c) dst[c] = row < Q ? src[c] : f4{0.f, 0.f, 0.f, 0.f};
+}
+
+struct FusedArgs {
+  int64_t Q;
+  int L;                 // 2 or 3 layers
+  int in, h1, h2;        // true widths (h2 unused for L == 2)
+  int c1;                // hidden chunks of layer 1 (h1 padded to 64*c1)
+  const float* x;        // [Q][32]
+  const float* dout;     // [Q][32] (backward)
+  float* out;            // [Q][32] (forward)
+  const float* wf[3];    // forward fragments per layer
+  const float* bfr[3];
+  const float* wt[3];    // transposed fragments (index = layer whose input gradient they produce; [0] unused)
+  int ks[3];             // forward k-steps per tile
+  int kst[3];            // k-steps of the transposed products
+  float* dW[3];
+  float* db[3];
+};
+
+// ---- forward -------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(64) void mlp_fwd_fused_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float tx[64 * F_LDX];
+  const int lane = threadIdx.x;
+  const int64_t nblk = (A.Q + 63) / 64;
+  for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+    stage_rows(A.x, rb * 64, A.Q, tx, lane);
+    fsync();
+    float bin[FT][8];
+#pragma unroll
+    for (int s = 0; s < FT; ++s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bin[s][k] = tx[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
+    f4 oacc[2][FT];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      f4 b;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = A.bfr[A.L - 1][((size_t)o * 4 + r) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < FT; ++s) oacc[o][s] = b;
+    }
+    if (A.L == 2) {
+      for (int c = 0; c < A.c1; ++c) {
+        FChunk h;
+        chunk_set_bias(h, A.bfr[0], 4 * c, lane);
+        facc<4, 8>(h.a, A.wf[0], 8, 4 * c, 0, lane, [&](int s, int k) { return bin[s][k]; });
+        chunk_act_only<ACT>(h);
+        facc<2, 16>(oacc, A.wf[1], A.ks[1], 0, 16 * c, lane, [&](int s, int k) { return h.a[k >> 2][s][k & 3]; });
+      }
+    } else {
+      FChunk h1, h2;
+      chunk_set_bias(h1, A.bfr[0], 0, lane);
+      facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      chunk_act_only<ACT>(h1);
+      chunk_set_bias(h2, A.bfr[1], 0, lane);
+      facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
+      chunk_act_only<ACT>(h2);
+      facc<2, 16>(oacc, A.wf[2], A.ks[2], 0, 0, lane, [&](int s, int k) { return h2.a[k >> 2][s][k & 3]; });
+    }
+    fsync();
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int s = 0; s < FT; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * o + 4 * (lane >> 4) + r;
+          tx[(16 * s + (lane & 15)) * F_LDX + u] = u < 25 ? oacc[o][s][r] : 0.f;
+        }
+    fsync();
+    const int64_t row = rb * 64 + lane;
+    if (row < A.Q) {
+      const f4* src = reinterpret_cast<const f4*>(tx + lane * F_LDX);
+      f4* dst = reinterpret_cast<f4*>(A.out + row * F_LDX);
+#pragma unroll
+      for (int c = 0; c < F_LDX / 4; ++c) dst[c] = src[c];
+    }
+    fsync();
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------
+// L == 3: one wave handles whole networks (H1, H2 <= 64) over its row blocks.
+// L == 2: wave w handles hidden chunk w % c1 over the row blocks w / c1, w / c1 + G / c1, ...
+template <int ACT, int L>
+__global__ __launch_bounds__(64) void mlp_bwd_fused_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float tx[64 * F_LDX];
+  __shared__ __attribute__((aligned(16))) float td[64 * F_LDX];
+  __shared__ __attribute__((aligned(16))) float tu[64 * F_LDH];
+  __shared__ __attribute__((aligned(16))) float tv[64 * F_LDH];
+  const int lane = threadIdx.x;
+  const int64_t nblk = (A.Q + 63) / 64;
+  const int nchunk = L == 2 ? A.c1 : 1;
+  const int chunk = blockIdx.x % nchunk;
+  const int64_t rb0 = blockIdx.x / nchunk, rbstep = gridDim.x / nchunk;
+  if (rb0 >= nblk || rbstep == 0) return;
+
+  // accumulators kept over all row blocks of this wave
+  f4 aW1[4][2];  // dW1 rows of this chunk x 32 input columns
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 aW2[4][4];  // L == 3: dW2 (64 x 64);  L == 2: [0..1][*] = dW2 (32 outputs x 64 hidden of this chunk)
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aW2[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 aW3[2][4];  // L == 3: dW3 (32 outputs x 64 hidden)
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aW3[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 pb1[4], pb2[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { pb1[o] = f4{0.f, 0.f, 0.f, 0.f}; pb2[o] = f4{0.f, 0.f, 0.f, 0.f}; }
+  float pbo = 0.f;  // bias gradient of the output layer, unit = lane (< 32), from the dOUT tile
+
+  for (int64_t rb = rb0; rb < nblk; rb += rbstep) {
+    stage_rows(A.x, rb * 64, A.Q, tx, lane);
+    stage_rows(A.dout, rb * 64, A.Q, td, lane);
+    fsync();
+    float bin[FT][8], bd[FT][8];
+#pragma unroll
+    for (int s = 0; s < FT; ++s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bin[s][k] = tx[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
+        bd[s][k] = td[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
+      }
+    if (L == 3 || chunk == 0) {
+      if (lane < 32) {
+        float sacc = 0.f;
+        for (int rr = 0; rr < 64; ++rr) sacc += td[rr * F_LDX + lane];
+        pbo += sacc;
+      }
+    }
+    if constexpr (L == 3) {
+      FChunk h1, g1, h2, g2;
+      chunk_set_bias(h1, A.bfr[0], 0, lane);
+      facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      chunk_act_grad<ACT>(h1, g1);
+      chunk_to_tile(tu, F_LDH, h1, lane);  // A1 [sample][unit]
+      chunk_set_bias(h2, A.bfr[1], 0, lane);
+      facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
+      chunk_act_grad<ACT>(h2, g2);
+      chunk_to_tile(tv, F_LDH, h2, lane);  // A2 [sample][unit]
+      fsync();
+      // dW3 += dOUT^T A2
+      wgrad<2, 4>(aW3, td, F_LDX, tv, F_LDH, lane);
+      // dZ2 = (W3^T dOUT) * act'(Z2)
+      FChunk d2;
+      chunk_zero(d2);
+      facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
+      chunk_mul(d2, g2);
+      bias_partial(pb2, d2);
+      // dZ1 = (W2^T dZ2) * act'(Z1)
+      FChunk d1;
+      chunk_zero(d1);
+      facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
+      chunk_mul(d1, g1);
+      bias_partial(pb1, d1);
+      fsync();
+      chunk_to_tile(tv, F_LDH, d2, lane);  // dZ2 [sample][unit] (A2 is consumed)
+      fsync();
+      wgrad<4, 4>(aW2, tv, F_LDH, tu, F_LDH, lane);  // dW2 += dZ2^T A1
+      fsync();
+      chunk_to_tile(tv, F_LDH, d1, lane);  // dZ1
+      fsync();
+      wgrad<4, 2>(aW1, tv, F_LDH, tx, F_LDX, lane);  // dW1 += dZ1^T X
+      fsync();
+    } else {
+      FChunk h1, g1;
+      chunk_set_bias(h1, A.bfr[0], 4 * chunk, lane);
+      facc<4, 8>(h1.a, A.wf[0], 8, 4 * chunk, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      chunk_act_grad<ACT>(h1, g1);
+      chunk_to_tile(tu, F_LDH, h1, lane);  // A1 chunk [sample][unit]
+      fsync();
+      // dW2[:, chunk] += dOUT^T A1
+      f4(&aWo)[2][4] = reinterpret_cast<f4(&)[2][4]>(aW2);
+      wgrad<2, 4>(aWo, td, F_LDX, tu, F_LDH, lane);
+      // dZ1 = (W2^T[chunk] dOUT) * act'(Z1)
+      FChunk d1;
+      chunk_zero(d1);
+      facc<4, 8>(d1.a, A.wt[1], A.kst[1], 4 * chunk, 0, lane, [&](int s, int k) { return bd[s][k]; });
+      chunk_mul(d1, g1);
+      bias_partial(pb1, d1);
+      chunk_to_tile(tv, F_LDH, d1, lane);
+      fsync();
+      wgrad<4, 2>(aW1, tv, F_LDH, tx, F_LDX, lane);  // dW1[chunk] += dZ1^T X
+      fsync();
+    }
+  }
+  // ---- one flush per wave ------------------------------------------------------------------------------
+  if constexpr (L == 3) {
+    wgrad_flush<2, 4>(aW3, A.dW[2], 25, A.h2, 0, 0, lane);
+    wgrad_flush<4, 4>(aW2, A.dW[1], A.h2, A.h1, 0, 0, lane);
+    wgrad_flush<4, 2>(aW1, A.dW[0], A.h1, A.in, 0, 0, lane);
+    bias_flush(pb2, A.db[1], A.h2, 0, lane);
+    bias_flush(pb1, A.db[0], A.h1, 0, lane);
+    if (lane < 25) atomicAdd(&A.db[2][lane], pbo);
+  } else {
+    const f4(&aWo)[2][4] = reinterpret_cast<const f4(&)[2][4]>(aW2);
+    wgrad_flush<2, 4>(aWo, A.dW[1], 25, A.h1, 0, 64 * chunk, lane);
+    wgrad_flush<4, 2>(aW1, A.dW[0], A.h1, A.in, 64 * chunk, 0, lane);
+    bias_flush(pb1, A.db[0], A.h1, 64 * chunk, lane);
+    if (chunk == 0 && lane < 25) atomicAdd(&A.db[1][lane], pbo);
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad) {
+  if (n_layers != 2 && n_layers != 3) return false;
+  if (in_pad != 32 || dims[0] > 32 || dims[n_layers] != 25) return false;
+  if (acts[n_layers - 1] != KR_ACT_NONE) return false;
+  if (n_layers == 3 && (dims[1] > 64 || dims[2] > 64 || acts[0] != acts[1])) return false;
+  return true;
+}
+
+// workspace for the packed fragments (floats)
+static size_t fused_frag_floats(int n_layers, const int32_t* dims) {
+  size_t n = 0;
+  int prev_tiles = 2;
+  for (int k = 0; k < n_layers; ++k) {
+    const bool last = k == n_layers - 1;
+    const int tiles = last ? 2 : ((dims[k + 1] + 63) / 64) * 4;
+    const int ks = k == 0 ? 8 : prev_tiles * 4;
+    n += (size_t)tiles * ks * 64 + (size_t)tiles * 4 * 64;        // forward + bias
+    if (k > 0) n += (size_t)prev_tiles * (last ? 8 : tiles * 4) * 64;  // transposed
+    prev_tiles = tiles;
+  }
+  return n;
+}
+size_t fused_ws_bytes(int n_layers, const int32_t* dims) { return fused_frag_floats(n_layers, dims) * sizeof(float) + 256; }
+
+// lays the fragment buffers out in `ws`; do_pack launches the packing kernels (forward call), otherwise
+// the fragments packed by the matching forward call are reused (backward call)
+static int fused_pack(FusedArgs& A, int n_layers, const int32_t* dims, const float* const* W, const float* const* b,
+                      float* ws, bool do_pack, hipStream_t s) {
+  A.L = n_layers;
+  A.in = dims[0];
+  A.h1 = dims[1];
+  A.h2 = n_layers == 3 ? dims[2] : 0;
+  A.c1 = (dims[1] + 63) / 64;
+  float* p = ws;
+  int prev_tiles = 2;
+  for (int k = 0; k < n_layers; ++k) {
+    const bool last = k == n_layers - 1;
+    const int tiles = last ? 2 : ((dims[k + 1] + 63) / 64) * 4;
+    const int ks = k == 0 ? 8 : prev_tiles * 4;
+    float* wf = p; p += (size_t)tiles * ks * 64;
+    float* bf = p; p += (size_t)tiles * 4 * 64;
+    if (do_pack)
+      hipLaunchKernelGGL(pack_fwd_kernel, dim3(64), dim3(256), 0, s, W[k], b[k], dims[k], dims[k + 1], tiles, ks,
+                         k == 0 ? 1 : 0, wf, bf);
+    A.wf[k] = wf; A.bfr[k] = bf; A.ks[k] = ks;
+    if (k > 0) {
+      // dA_{k-1}[in unit][sample] = sum_out W_k[out][in] dZ_k[out][sample]: k-steps run over the outputs of layer k
+      const int kst = last ? 8 : tiles * 4;
+      float* wt = p; p += (size_t)prev_tiles * kst * 64;
+      if (do_pack)
+        hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, s, W[k], dims[k], dims[k + 1], prev_tiles, kst,
+                           last ? 1 : 0, wt);
+      A.wt[k] = wt; A.kst[k] = kst;
+    }
+    prev_tiles = tiles;
+  }
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+template <typename K>
+static void launch_by_act(int act, K&& fn) {
+  switch (act) {
+    case KR_ACT_TANH: fn(std::integral_constant<int, KR_ACT_TANH>{}); break;
+    case KR_ACT_SOFTPLUS: fn(std::integral_constant<int, KR_ACT_SOFTPLUS>{}); break;
+    case KR_ACT_RELU: fn(std::integral_constant<int, KR_ACT_RELU>{}); break;
+    case KR_ACT_ELU: fn(std::integral_constant<int, KR_ACT_ELU>{}); break;
+    default: fn(std::integral_constant<int, KR_ACT_NONE>{}); break;
+  }
+}
+
+int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
+                      const float* const* b, const float* x, float* out, void* ws, hipStream_t s) {
+  FusedArgs A{};
+  A.Q = Q; A.x = x; A.out = out;
+  int rc = fused_pack(A, n_layers, dims, W, b, static_cast<float*>(ws), true, s);
+  if (rc) return rc;
+  const int64_t nblk = (Q + 63) / 64;
+  const int grid = (int)(nblk < 2048 ? nblk : 2048);
+  launch_by_act(acts[0], [&](auto act) {
+    hipLaunchKernelGGL((mlp_fwd_fused_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
+  });
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
+                       const float* x, const float* dout, void* ws, float* const* dW, float* const* db,
+                       hipStream_t s) {
+  FusedArgs A{};
+  A.Q = Q; A.x = x; A.dout = dout;
+  for (int k = 0; k < n_layers; ++k) { A.dW[k] = dW[k]; A.db[k] = db[k]; }
+  int rc = fused_pack(A, n_layers, dims, W, nullptr, static_cast<float*>(ws), false, s);
+  if (rc) return rc;
+  const int64_t nblk = (Q + 63) / 64;
+  const int nchunk = n_layers == 2 ? A.c1 : 1;
+  int64_t waves = nblk * nchunk;
+  if (waves > 768) waves = 768 / nchunk * nchunk;  // 3 workgroups of 48 KB LDS per CU
+  if (waves < nchunk) waves = nchunk;
+  const int grid = (int)waves;
+  launch_by_act(acts[0], [&](auto act) {
+    if (n_layers == 3)
+      hipLaunchKernelGGL((mlp_bwd_fused_kernel<decltype(act)::value, 3>), dim3(grid), dim3(64), 0, s, A);
+    else
+      hipLaunchKernelGGL((mlp_bwd_fused_kernel<decltype(act)::value, 2>), dim3(grid), dim3(64), 0, s, A);
+  });
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+}  // namespace kr

@@ -426,7 +426,12 @@ int kr_next_segment_physics(kr_handle* h, int64_t S, int K, const void* Gs, cons
 
 size_t kr_mlp_ws_bytes(int n_layers, const int32_t* dims, int64_t Q) {
   if (n_layers < 1 || n_layers > KR_MAX_LAYERS || !dims || Q <= 0) return 0;
-  return carve_ws(nullptr, n_layers, dims, Q).bytes;
+  size_t n = carve_ws(nullptr, n_layers, dims, Q).bytes;
+  if (n_layers == 2 || n_layers == 3) {
+    const size_t f = fused_ws_bytes(n_layers, dims);
+    if (f > n) n = f;
+  }
+  return n;
 }
 
 int kr_mlp_forward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts,
@@ -446,6 +451,10 @@ int kr_mlp_forward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, c
   }
   if (Q > (int64_t)1 << 30) { set_error("Q too large"); return KR_E_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->fused_mlp && fused_mlp_supported(n_layers, dims, acts, in_pad)) {
+    KR_CHECK_PTR(ws);
+    return fused_mlp_forward(Q, n_layers, dims, acts, W, b, x, out, ws, s);
+  }
   MlpWs w = carve_ws(ws, n_layers, dims, Q);
   const float* in = x;
   int64_t ld_in = in_pad;
@@ -488,6 +497,8 @@ int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, 
   if (Q == 0) return KR_OK;
   KR_CHECK_PTR(x); KR_CHECK_PTR(dout);
   if (n_layers > 1) KR_CHECK_PTR(ws);
+  if (acts[n_layers - 1] == KR_ACT_NONE && h->fused_mlp && fused_mlp_supported(n_layers, dims, acts, in_pad))
+    return fused_mlp_backward(Q, n_layers, dims, acts, W, x, dout, const_cast<void*>(ws), dW, db, s);
   MlpWs w = carve_ws(const_cast<void*>(ws), n_layers, dims, Q);
   const float* dz = dout;  // d loss / d (pre-activation of layer k); the last layer has no activation
   int64_t ld_dz = 32;
