@@ -252,6 +252,15 @@ int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, 
 int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const float* out, const float* target,
                     const int32_t* idx, double denom, float* pred, float* loss, float* dout, void* stream);
 
+/* The same loss against pre-gathered targets: the states a training set is scored against never
+ * change between epochs, so kr_gather_targets extracts rows[S*K][25] once (y rows at column idx[k],
+ * z rows at idx[k]-1) and kr_loss_rows_fwd_bwd reads them contiguously.  pred may be NULL. */
+int kr_gather_targets(kr_handle* h, int64_t S, int K, const float* target, const int32_t* idx, float* rows,
+                      void* stream);
+int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const float* out,
+                         const float* target_rows, double denom, float* pred, float* loss, float* dout,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,26 @@ __device__ __forceinline__ void chunk_act_only(FChunk& z) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) z.a[o][s][r] = activate<float>(ACT, z.a[o][s][r]);
 }
+// act'(z) expressed through a = act(z) (so only the activations need to be kept, in their LDS tile)
+template <int ACT>
+__device__ __forceinline__ float grad_from_act(float a) {
+  if constexpr (ACT == KR_ACT_ELU) return a > 0.f ? 1.f : a + 1.f;       // exp(z) = a + 1 for z <= 0
+  else if constexpr (ACT == KR_ACT_TANH) return 1.f - a * a;
+  else if constexpr (ACT == KR_ACT_SOFTPLUS) return 1.f - __expf(-a);    // sigmoid(z) = 1 - exp(-softplus(z))
+  else if constexpr (ACT == KR_ACT_RELU) return a > 0.f ? 1.f : 0.f;
+  else return 1.f;
+}
+// d *= act'(z), with act(z) read back from its LDS tile [sample][unit] (row length ld, units tile0*16..)
+template <int ACT>
+__device__ __forceinline__ void chunk_mul_grad(FChunk& d, const float* tile, int ld, int lane) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        d.a[o][s][r] *= grad_from_act<ACT>(tile[(16 * s + (lane & 15)) * ld + 16 * o + 4 * (lane >> 4) + r]);
+}
 __device__ __forceinline__ void chunk_mul(FChunk& d, const FChunk& g) {
 #pragma unroll
   for (int o = 0; o < 4; ++o)
@@ -197,6 +217,14 @@ __device__ __forceinline__ void bias_flush(const f4 (&p)[4], float* __restrict__
       const int u = out0 + 16 * o + 4 * (lane >> 4) + r;
       if ((lane & 15) == 0 && u < out) atomicAdd(&db[u], v);
     }
+}
+
+// B operands (natural k order) of the four sample tiles from an LDS tile [sample][32]
+__device__ __forceinline__ void load_bops(float (&b)[FT][8], const float* tile, int lane) {
+#pragma unroll
+  for (int s = 0; s < FT; ++s)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[s][k] = tile[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
 }
 
 // rows [row0, row0+64) of a row-major [Q][32] array -> LDS tile (zero beyond Q)
@@ -329,14 +357,6 @@ __global__ __launch_bounds__(64) void mlp_bwd_fused_kernel(const FusedArgs A) {
     stage_rows(A.x, rb * 64, A.Q, tx, lane);
     stage_rows(A.dout, rb * 64, A.Q, td, lane);
     fsync();
-    float bin[FT][8], bd[FT][8];
-#pragma unroll
-    for (int s = 0; s < FT; ++s)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        bin[s][k] = tx[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
-        bd[s][k] = td[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
-      }
     if (L == 3 || chunk == 0) {
       if (lane < 32) {
         float sacc = 0.f;
@@ -345,45 +365,60 @@ __global__ __launch_bounds__(64) void mlp_bwd_fused_kernel(const FusedArgs A) {
       }
     }
     if constexpr (L == 3) {
-      FChunk h1, g1, h2, g2;
-      chunk_set_bias(h1, A.bfr[0], 0, lane);
-      facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
-      chunk_act_grad<ACT>(h1, g1);
-      chunk_to_tile(tu, F_LDH, h1, lane);  // A1 [sample][unit]
-      chunk_set_bias(h2, A.bfr[1], 0, lane);
-      facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
-      chunk_act_grad<ACT>(h2, g2);
-      chunk_to_tile(tv, F_LDH, h2, lane);  // A2 [sample][unit]
+      {
+        FChunk h1;
+        {
+          float bin[FT][8];
+          load_bops(bin, tx, lane);
+          chunk_set_bias(h1, A.bfr[0], 0, lane);
+          facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
+        }
+        chunk_act_only<ACT>(h1);
+        chunk_to_tile(tu, F_LDH, h1, lane);  // A1 [sample][unit]
+        FChunk h2;
+        chunk_set_bias(h2, A.bfr[1], 0, lane);
+        facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
+        chunk_act_only<ACT>(h2);
+        chunk_to_tile(tv, F_LDH, h2, lane);  // A2 [sample][unit]
+      }
       fsync();
       // dW3 += dOUT^T A2
       wgrad<2, 4>(aW3, td, F_LDX, tv, F_LDH, lane);
       // dZ2 = (W3^T dOUT) * act'(Z2)
       FChunk d2;
       chunk_zero(d2);
-      facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
-      chunk_mul(d2, g2);
+      {
+        float bd[FT][8];
+        load_bops(bd, td, lane);
+        facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
+      }
+      chunk_mul_grad<ACT>(d2, tv, F_LDH, lane);
       bias_partial(pb2, d2);
-      // dZ1 = (W2^T dZ2) * act'(Z1)
-      FChunk d1;
-      chunk_zero(d1);
-      facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
-      chunk_mul(d1, g1);
-      bias_partial(pb1, d1);
       fsync();
       chunk_to_tile(tv, F_LDH, d2, lane);  // dZ2 [sample][unit] (A2 is consumed)
       fsync();
       wgrad<4, 4>(aW2, tv, F_LDH, tu, F_LDH, lane);  // dW2 += dZ2^T A1
+      // dZ1 = (W2^T dZ2) * act'(Z1)
+      FChunk d1;
+      chunk_zero(d1);
+      facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
+      chunk_mul_grad<ACT>(d1, tu, F_LDH, lane);
+      bias_partial(pb1, d1);
       fsync();
       chunk_to_tile(tv, F_LDH, d1, lane);  // dZ1
       fsync();
       wgrad<4, 2>(aW1, tv, F_LDH, tx, F_LDX, lane);  // dW1 += dZ1^T X
       fsync();
     } else {
-      FChunk h1, g1;
-      chunk_set_bias(h1, A.bfr[0], 4 * chunk, lane);
-      facc<4, 8>(h1.a, A.wf[0], 8, 4 * chunk, 0, lane, [&](int s, int k) { return bin[s][k]; });
-      chunk_act_grad<ACT>(h1, g1);
-      chunk_to_tile(tu, F_LDH, h1, lane);  // A1 chunk [sample][unit]
+      {
+        FChunk h1;
+        float bin[FT][8];
+        load_bops(bin, tx, lane);
+        chunk_set_bias(h1, A.bfr[0], 4 * chunk, lane);
+        facc<4, 8>(h1.a, A.wf[0], 8, 4 * chunk, 0, lane, [&](int s, int k) { return bin[s][k]; });
+        chunk_act_only<ACT>(h1);
+        chunk_to_tile(tu, F_LDH, h1, lane);  // A1 chunk [sample][unit]
+      }
       fsync();
       // dW2[:, chunk] += dOUT^T A1
       f4(&aWo)[2][4] = reinterpret_cast<f4(&)[2][4]>(aW2);
@@ -391,8 +426,12 @@ __global__ __launch_bounds__(64) void mlp_bwd_fused_kernel(const FusedArgs A) {
       // dZ1 = (W2^T[chunk] dOUT) * act'(Z1)
       FChunk d1;
       chunk_zero(d1);
-      facc<4, 8>(d1.a, A.wt[1], A.kst[1], 4 * chunk, 0, lane, [&](int s, int k) { return bd[s][k]; });
-      chunk_mul(d1, g1);
+      {
+        float bd[FT][8];
+        load_bops(bd, td, lane);
+        facc<4, 8>(d1.a, A.wt[1], A.kst[1], 4 * chunk, 0, lane, [&](int s, int k) { return bd[s][k]; });
+      }
+      chunk_mul_grad<ACT>(d1, tu, F_LDH, lane);
       bias_partial(pb1, d1);
       chunk_to_tile(tv, F_LDH, d1, lane);
       fsync();

@@ -241,6 +241,21 @@ static MlpWs carve_ws(void* ws, int n_layers, const int32_t* dims, int64_t Q) {
   return w;
 }
 
+// gathers the target values every (s, k) row is scored against: rows[s*K+k][r] = target[s][r][idx[k]] for the
+// y rows, target[s][r][idx[k]-1] for the z rows (physics_train.py:252-259)
+__global__ void gather_targets_kernel(int N, int64_t S, int K, const float* __restrict__ target,
+                                      const int32_t* __restrict__ idx, float* __restrict__ rows) {
+  const int64_t n = S * K * 25;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i % 25);
+    const int64_t row = i / 25;
+    const int64_t s = row / K;
+    const int k = (int)(row - s * K);
+    const int j = r < 19 ? idx[k] : idx[k] - 1;
+    rows[i] = target[(s * 25 + r) * (int64_t)N + j];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // T4: prediction + four-term loss + gradient w.r.t. the MLP output
 // ---------------------------------------------------------------------------
@@ -283,6 +298,8 @@ __device__ __forceinline__ void q2e_vjp(const float q[4], const float ge[3], flo
   gq[3] = (gn[3] - z * dot) * inv;
 }
 
+// ROWS: `target` holds pre-gathered rows [S*K][25] (kr_gather_targets) instead of the full [S][25][N] states
+template <bool ROWS>
 __global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, int K, const float* __restrict__ base,
                                                    const float* __restrict__ out, int ld_out,
                                                    const float* __restrict__ target, const int32_t* __restrict__ idx,
@@ -297,33 +314,45 @@ __global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, i
        row += (int64_t)gridDim.x * blockDim.x) {
     const int64_t s = row / K;
     const int k = (int)(row - s * K);
-    const int jc = idx[k];
+    float tgv[25];  // target values of this row: y rows at column idx[k], z rows at idx[k]-1 (physics_train.py:259)
+    if constexpr (ROWS) {
+#pragma unroll
+      for (int r = 0; r < 25; ++r) tgv[r] = target[row * 25 + r];
+    } else {
+      const int jc = idx[k];
+      const float* tg = target + s * 25 * (int64_t)N;
+#pragma unroll
+      for (int r = 0; r < 19; ++r) tgv[r] = tg[r * N + jc];
+#pragma unroll
+      for (int r = 19; r < 25; ++r) tgv[r] = tg[r * N + (jc - 1)];
+    }
     float p[25], g[25];
 #pragma unroll
     for (int r = 0; r < 19; ++r) p[r] = base[row * 25 + r] + ds * out[row * ld_out + r];
 #pragma unroll
     for (int r = 19; r < 25; ++r) p[r] = base[row * 25 + r] + out[row * ld_out + r];
+    if (pred) {
 #pragma unroll
-    for (int r = 0; r < 25; ++r) pred[row * 25 + r] = p[r];
-    const float* tg = target + s * 25 * (int64_t)N;
+      for (int r = 0; r < 25; ++r) pred[row * 25 + r] = p[r];
+    }
     // positions, physics_train.py:252-253
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const float d = p[r] - tg[r * N + jc];
+      const float d = p[r] - tgv[r];
       part += w_p * d * d;
       g[r] = 2.f * w_p * d;
     }
     // n m q w, :254-255
 #pragma unroll
     for (int r = 7; r < 19; ++r) {
-      const float d = p[r] - tg[r * N + jc];
+      const float d = p[r] - tgv[r];
       part += w_r * d * d;
       g[r] = 2.f * w_r * d;
     }
     // Euler angles of the quaternion, :256-257
     {
       float qp[4] = {p[3], p[4], p[5], p[6]};
-      float qt[4] = {tg[3 * N + jc], tg[4 * N + jc], tg[5 * N + jc], tg[6 * N + jc]};
+      float qt[4] = {tgv[3], tgv[4], tgv[5], tgv[6]};
       float ep[3], et[3], ge[3], gq[4];
       q2e(qp, ep);
       q2e(qt, et);
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, i
     // z rows against the column before the key point, :258-259
 #pragma unroll
     for (int r = 19; r < 25; ++r) {
-      const float d = p[r] - tg[r * N + (jc - 1)];
+      const float d = p[r] - tgv[r];
       part += w_z * d * d;
       g[r] = 2.f * w_z * d;
     }
@@ -568,8 +597,42 @@ int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const flo
   const int64_t rows = S * K;
   int grid = (int)((rows + 255) / 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, s, h->params.N, (float)h->derived.ds, S, K, base, out, 32,
-                     target, idx, (float)(1.0 / denom), pred, loss, dout, 32);
+  hipLaunchKernelGGL(loss_kernel<false>, dim3(grid), dim3(256), 0, s, h->params.N, (float)h->derived.ds, S, K, base, out,
+                     32, target, idx, (float)(1.0 / denom), pred, loss, dout, 32);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+int kr_gather_targets(kr_handle* h, int64_t S, int K, const float* target, const int32_t* idx, float* rows,
+                      void* stream) {
+  KR_CHECK_H(h);
+  if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
+  if (S == 0 || K == 0) return KR_OK;
+  KR_CHECK_PTR(target); KR_CHECK_PTR(idx); KR_CHECK_PTR(rows);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n = S * K * 25;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(gather_targets_kernel, dim3(grid), dim3(256), 0, s, h->params.N, S, K, target, idx, rows);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const float* out, const float* target_rows,
+                         double denom, float* pred, float* loss, float* dout, void* stream) {
+  KR_CHECK_H(h);
+  if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
+  KR_CHECK_PTR(loss);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KR_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+  if (S == 0 || K == 0) return KR_OK;
+  KR_CHECK_PTR(base); KR_CHECK_PTR(out); KR_CHECK_PTR(target_rows); KR_CHECK_PTR(dout);
+  if (!(denom > 0)) { set_error("denom must be positive"); return KR_E_ARG; }
+  const int64_t rows = S * K;
+  int grid = (int)((rows + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(loss_kernel<true>, dim3(grid), dim3(256), 0, s, h->params.N, (float)h->derived.ds, S, K, base, out,
+                     32, target_rows, (const int32_t*)nullptr, (float)(1.0 / denom), pred, loss, dout, 32);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }

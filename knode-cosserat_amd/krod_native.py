@@ -82,6 +82,8 @@ _PROTOS = {
     "kr_mlp_forward": (_int, [_vp, _i64, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), C.POINTER(_vp), _vp, _int, _vp, _vp, _vp]),
     "kr_mlp_backward": (_int, [_vp, _i64, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), _vp, _int, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "kr_loss_fwd_bwd": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "kr_gather_targets": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "kr_loss_rows_fwd_bwd": (_int, [_vp, _i64, _int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

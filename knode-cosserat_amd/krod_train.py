@@ -72,8 +72,9 @@ class KnodeTrainer:
     """
 
     def __init__(self, robot, trajs, controls, key_pt_idx, lr=1e-2, weight_decay=0.0, clamp_weights=True,
-                 patience=80, factor=0.5, group=None):
+                 patience=80, factor=0.5, group=None, keep_pred=True):
         self.robot = robot
+        self.keep_pred = keep_pred  # write the predictions of every epoch (needed only by predictions())
         self.group = group
         self.clamp_weights = clamp_weights
         h = robot._native()
@@ -104,6 +105,11 @@ class KnodeTrainer:
         self.Q = Q
         self.x = torch.empty((Q, self.in_pad), dtype=torch.float32, device=dev)
         self.base = torch.empty((Q, 25), dtype=torch.float32, device=dev)
+        # target values of every scored row, gathered once (they do not change between epochs)
+        self.target_rows = torch.empty((max(Q, 1), 25), dtype=torch.float32, device=dev)
+        if Q:
+            kn.check(h.lib.kr_gather_targets(h._h, S, self.K, kn._ptr(self.target), kn._ptr(self.idx_t),
+                                             kn._ptr(self.target_rows), kn._stream()))
         if Q:
             kn.check(h.lib.kr_next_segment_physics(h._h, S, self.K, kn._ptr(self.target), kn._ptr(yh), kn._ptr(zh),
                                                    kn._ptr(tens), kn._ptr(self.idx_t), kn._ptr(self.x), self.in_pad,
@@ -145,9 +151,10 @@ class KnodeTrainer:
         Q = self.Q
         kn.check(h.lib.kr_mlp_forward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, bp, kn._ptr(self.x), self.in_pad,
                                       kn._ptr(self.out), kn._ptr(self.ws), s))
-        kn.check(h.lib.kr_loss_fwd_bwd(h._h, self.S, self.K, kn._ptr(self.base), kn._ptr(self.out),
-                                       kn._ptr(self.target), kn._ptr(self.idx_t), float(self.steps),
-                                       kn._ptr(self.pred), kn._ptr(self.bucket.loss), kn._ptr(self.dout), s))
+        kn.check(h.lib.kr_loss_rows_fwd_bwd(h._h, self.S, self.K, kn._ptr(self.base), kn._ptr(self.out),
+                                            kn._ptr(self.target_rows), float(self.steps),
+                                            kn._ptr(self.pred) if self.keep_pred else None,
+                                            kn._ptr(self.bucket.loss), kn._ptr(self.dout), s))
         kn.check(h.lib.kr_mlp_backward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, kn._ptr(self.x), self.in_pad,
                                        kn._ptr(self.dout), kn._ptr(self.ws), dWp, dbp, s))
         self.bucket.all_reduce(self.group)

@@ -252,6 +252,21 @@ def test_loss_kernel_vs_torch_autograd(torch_cuda):
     assert rel_l2(pred.cpu().numpy(), p.detach().float().cpu().numpy()) < 1e-6
     assert rel_l2(dout[:, :25].cpu().numpy(), o.grad[:, :25].cpu().numpy()) < 5e-5
     assert float(dout[:, 25:].abs().max()) == 0.0
+    # pre-gathered target rows (kr_gather_targets + kr_loss_rows_fwd_bwd) give the same numbers bit for bit
+    rows = torch.empty((S * K, 25), dtype=torch.float32, device=DEV)
+    kn.check(h.lib.kr_gather_targets(h._h, S, K, kn._ptr(target), kn._ptr(idx_t), kn._ptr(rows), kn._stream()))
+    want = torch.cat([target[:, :19][:, :, kp], target[:, 19:][:, :, kp - 1]], dim=1).transpose(1, 2).reshape(S * K, 25)
+    assert torch.equal(rows, want)
+    dout2 = torch.empty_like(dout)
+    loss2 = torch.zeros_like(loss)
+    for pr in (pred.clone().zero_(), None):
+        kn.check(h.lib.kr_loss_rows_fwd_bwd(h._h, S, K, kn._ptr(base), kn._ptr(out), kn._ptr(rows), 29.0,
+                                            kn._ptr(pr) if pr is not None else None, kn._ptr(loss2),
+                                            kn._ptr(dout2), kn._stream()))
+        assert torch.equal(dout2, dout)
+        assert abs(loss2.item() - loss.item()) <= 1e-6 * abs(loss.item())  # atomics: order of the block sums
+        if pr is not None:
+            assert torch.equal(pr, pred)
 
 
 def test_ode_parallel_and_pickle(torch_cuda):

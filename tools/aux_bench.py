@@ -49,7 +49,7 @@ if "train" in what:
                 if isinstance(m, nn.Linear):
                     rob.non_negative_normal_init(m, 0.01, 0.01); nn.init.normal_(m.bias, 0.0, 0.01)
             rob.nn_models = nn.ModuleList(mods).to(dev)
-        tr = KnodeTrainer(rob, traj, controls, kp)
+        tr = KnodeTrainer(rob, traj, controls, kp, keep_pred=False)
         t_fb = timeit(lambda: tr.loss_and_grads(), reps=5, inner=5)
         t_ep = timeit(lambda: tr.step(sync_loss=False), reps=5, inner=5)
         dims = [28] + layers + [25]
