@@ -481,7 +481,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   const int N = Pc.N;
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = threadIdx.x / WAVE;
-  const int64_t rod = (int64_t)blockIdx.x * MS_WPB + wv;
+  const int64_t rod = (int64_t)blockIdx.x * (blockDim.x / WAVE) + wv;  // 4, 2 or 1 rods per workgroup (ms_wpb)
   if (rod >= A.B) return;  // whole wavefront; there is no workgroup barrier in this kernel
   const size_t rod_elems = (size_t)N * KR_SLOTS;
   const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, false, NN), N, false);
@@ -673,21 +673,32 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
 }
 
 template <typename T, int HS>
-static size_t ms_lds_bytes(int N, bool persist = false, bool nn = false) {
-  return sizeof(T) * ms_lds_elems<T, HS>(N, persist, nn) * MS_WPB;
+static size_t ms_lds_bytes(int N, bool persist = false, bool nn = false, int wpb = MS_WPB) {
+  return sizeof(T) * ms_lds_elems<T, HS>(N, persist, nn) * wpb;
+}
+// rods per workgroup of the per-step kernel: as many as the LDS history of N grid points allows (long rods
+// get 2 or 1, e.g. fp64 N=400 needs 58 KB per rod); 0 = does not fit at all
+template <typename T, int HS>
+static int ms_wpb(int N, bool nn, size_t lds_limit) {
+  for (int w = MS_WPB; w >= 1; w >>= 1)
+    if (ms_lds_bytes<T, HS>(N, false, nn, w) <= lds_limit) return w;
+  return 0;
 }
 
 template <typename T, bool DIAG, int SCHEME, bool NN>
-static int launch_ms_inst(const RodConst<T>& P, const MlpDev<T>& M, const StepArgs<T>& a, hipStream_t s) {
+static int launch_ms_inst(const RodConst<T>& P, const MlpDev<T>& M, const StepArgs<T>& a, size_t lds_limit,
+                          hipStream_t s) {
   auto kern = ms_step_kernel<T, DIAG, SCHEME, hs_phys<T>(), NN>;
-  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, false, NN);
+  const int wpb = ms_wpb<T, hs_phys<T>()>(P.N, NN, lds_limit);
+  if (wpb <= 0) { set_error("multiple-shooting kernel: history of N grid points does not fit in LDS"); return KR_E_ARG; }
+  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, false, NN, wpb);
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
     configured = smem;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a, M);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + wpb - 1) / wpb)), dim3(WAVE * wpb), smem, s, P, a, M);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }
@@ -703,7 +714,7 @@ static bool ms_eligible(kr_handle* h, int use_nn, const StepArgs<T>& a) {
   }
   if (h->ms_mode == 0) return false;
   if (P.N - 1 < 2 * MS_P) return false;                 // too few segments to cut
-  if (ms_lds_bytes<T, hs_phys<T>()>(P.N, false, use_nn != 0) > (size_t)h->lds_limit) return false;
+  if (ms_wpb<T, hs_phys<T>()>(P.N, use_nn != 0, (size_t)h->lds_limit) <= 0) return false;
   if (h->ms_mode == 1) return true;                     // forced
   return a.B <= (int64_t)h->ms_batch_limit;             // auto: latency mode for small batches
 }
@@ -713,9 +724,11 @@ static int launch_ms_nn(kr_handle* h, int scheme, const StepArgs<T>& a, hipStrea
   const RodConst<T>& P = consts<T>(h);
   const MlpDev<T>& M = mlpdev<T>(h);
   if (scheme == KR_EULER)
-    return P.diag ? launch_ms_inst<T, true, KR_EULER, NN>(P, M, a, s) : launch_ms_inst<T, false, KR_EULER, NN>(P, M, a, s);
+    return P.diag ? launch_ms_inst<T, true, KR_EULER, NN>(P, M, a, (size_t)h->lds_limit, s)
+                  : launch_ms_inst<T, false, KR_EULER, NN>(P, M, a, (size_t)h->lds_limit, s);
   if (scheme == KR_RK4)
-    return P.diag ? launch_ms_inst<T, true, KR_RK4, NN>(P, M, a, s) : launch_ms_inst<T, false, KR_RK4, NN>(P, M, a, s);
+    return P.diag ? launch_ms_inst<T, true, KR_RK4, NN>(P, M, a, (size_t)h->lds_limit, s)
+                  : launch_ms_inst<T, false, KR_RK4, NN>(P, M, a, (size_t)h->lds_limit, s);
   set_error("unknown scheme");
   return KR_E_ARG;
 }
