@@ -21,10 +21,14 @@
 // The initial guess comes from extrapolating the previous states in time
 // (order 0/1/2), which saves one Newton sweep per step on smooth inputs.
 #pragma once
+#include <type_traits>
 #include "kr_sim_impl.hpp"
 
 namespace kr {
 
+#ifndef KR_MS_UNROLL
+#define KR_MS_UNROLL 2  // grid points per trip of the non-storing sweep loop (lets the scheduler overlap neighbours)
+#endif
 constexpr int MS_P = 4;
 constexpr int MS_WPB = 4;  // wavefronts (= rods) per workgroup: the CU puts the 4 waves of a workgroup on its 4 SIMDs
 
@@ -34,6 +38,54 @@ constexpr int MS_WPB = 4;  // wavefronts (= rods) per workgroup: the CU puts the
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
+}
+// two adjacent values at an even element offset of a 16-byte aligned array: one LDS access
+template <typename T>
+__device__ __forceinline__ void store_pair(T* dst, T a, T b) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  V2 v;
+  v[0] = a; v[1] = b;
+  *reinterpret_cast<V2*>(dst) = v;
+}
+// value of the lane whose index differs by the quad permutation CTRL (0xB1: ^1, 0x4E: ^2), by DPP
+template <int CTRL>
+__device__ __forceinline__ float quad_xor(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_xor(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// |u| / max(|x|, 1) in fp32 (hardware reciprocal); +inf for a NaN or infinite update
+template <typename T>
+__device__ __forceinline__ float update_ratio(T u, T x) {
+  const float q = fabsf((float)u) * __builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
+  return q <= 3.0e38f ? q : __builtin_inff();
+}
+// maximum of a non-negative value over the 64 lanes (all active), DPP within rows of 16 then 4 readlanes
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad: lanes ^1
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad: lanes ^2
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+template <typename T>
+__device__ __forceinline__ void load_pair(const T* src, T& a, T& b) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const V2 v = *reinterpret_cast<const V2*>(src);
+  a = v[0]; b = v[1];
 }
 constexpr int MS_YP = 19;  // length of a state vector in LDS (row order p h n m q w)
 constexpr int MS_NCOL = 6 + 16 * (MS_P - 1);  // Jacobian columns of all intervals, packed
@@ -56,9 +108,9 @@ enum : int {
 // LDS elements of one rod (a multiple of 4, so every rod's slice stays 16-byte aligned)
 template <typename T, int HS>
 __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = false) {
-  // XB, Tm, IH, Es are contiguous; with the MLP on the same region doubles as the 64 x 32 exchange
+  // XB, Tm, Es are contiguous; with the MLP on the same region doubles as the 64 x 32 exchange
   // tile of mlp_mfma.hpp.  The cold table sits in front of XB so the tile cannot clobber it.
-  size_t alg = (MS_YP + 1) * 8 + 48 + WAVE + ((WAVE * MS_YP + 3) & ~3);
+  size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);
   if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
   size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + alg;
   if (persist) n += (size_t)N * 12 + 3 * MS_P * MS_YP;
@@ -68,7 +120,7 @@ __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = fa
 #ifdef KR_MS_STAMPS
 #define KR_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); (var) = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define KR_STAMP_ADD(acc, t0) do { unsigned long long _t; KR_STAMP(_t); (acc) += _t - (t0); (t0) = _t; } while (0)
-struct MsStamps { unsigned long long sweep = 0, alg = 0, prep = 0, total = 0; int its = 0; double dn[4] = {0, 0, 0, 0}; };
+struct MsStamps { unsigned long long sweep = 0, alg = 0, prep = 0, total = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0; int its = 0; double dn[4] = {0, 0, 0, 0}; };
 #else
 #define KR_STAMP(var) do { } while (0)
 #define KR_STAMP_ADD(acc, t0) do { } while (0)
@@ -163,10 +215,9 @@ template <typename T>
 struct MsLds {
   T* hist;  // [N][HS]
   T* Xs;    // [P][MS_YP]      start states (row order p h n m q w); the unknowns
-  T* Es;    // [64][MS_YP]     end state of every lane's sweep
-  T* IH;    // [64]            1 / forward-difference step of every lane
-  T* XB;    // [MS_YP+1][8]    one condensed block X_g = [a_g | M_g], published row by row
-  T* Tm;    // [6][8]          the 6x7 system for dG
+  T* Es;    // [64][MS_YP]     per lane: end state (unperturbed lanes) or forward-difference column
+  T* XB;    // [2][MS_YP][8]   condensed block X_g = [a_g | M_g], ping-pong between stages
+  T* Tm;    // [6][8]          rows [rhs | T] of the 6x6 system for dG
   T* cold;  // [CD_SIZE]       per-step parameters (see ms_cold_fill)
   T* c12;   // persistent kernel only: [N][12] leading slots (q w v u) of the newest state
 };
@@ -178,9 +229,8 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist) {
   // everything accessed with 16-byte vectors sits at a multiple of 4 elements
   L.cold = L.Xs + ((MS_P * MS_YP + 3) & ~3);
   L.XB = L.cold + ((CD_SIZE + 3) & ~3);
-  L.Tm = L.XB + (MS_YP + 1) * 8;
-  L.IH = L.Tm + 48;
-  L.Es = L.IH + WAVE;
+  L.Tm = L.XB + 2 * MS_YP * 8;
+  L.Es = L.Tm + 48;
   L.c12 = persist ? L.Es + ((WAVE * MS_YP + 3) & ~3) : nullptr;
   return L;
 }
@@ -206,7 +256,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
   unsigned long long tq;
   KR_STAMP(tq);
 #endif
-  T* Xs = L.Xs; T* Es = L.Es; T* IH = L.IH; T* XB = L.XB; T* Tm = L.Tm;
+  T* Xs = L.Xs; T* Es = L.Es; T* XB = L.XB; T* Tm = L.Tm;
   const int iv = R.iv, col = R.col;
   const bool idle = R.idle;
   bool storing = false, flush = false;
@@ -233,16 +283,15 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     // ---- sweep over this lane's sub-interval --------------------------------
     T hv[HS];
     load_hist_vec<T, HS>(C.hbase + (size_t)R.s_i * HS, hv);
-    for (int t = 0; t < R.lmax; ++t) {
-      // with the MLP on every lane must reach the wave-wide matrix-core call: lanes past the end of
-      // their (shorter) interval keep running on the last grid point and simply do not commit
-      const bool live = t < R.len_i;
-      if (NN || live) {
-        const int j = live ? R.s_i + t : R.s_i + R.len_i - 1;
-        const RodState<T> y_in = y;
-        RodState<T> k1;
-        V3<T> v, u;
-        eval_point<T, DIAG, NN, HS>(Pc, M, C, y, hv, k1, v, u);
+    // one grid point: evaluate, (on the accepted sweep, unperturbed lanes) stream the record out, advance.
+    // STORE is a compile-time tag so that the other sweeps run a branch-free body the scheduler can
+    // overlap across consecutive grid points.
+    auto point = [&](auto store_tag, int j, bool live) __attribute__((always_inline)) {
+      constexpr bool STORE = decltype(store_tag)::value;
+      RodState<T> k1;
+      V3<T> v, u;
+      eval_point<T, DIAG, NN, HS>(Pc, M, C, y, hv, k1, v, u);
+      if constexpr (STORE) {
         if (st && live) {
           T rec[KR_SLOTS];
           record_from(y, v, u, rec);
@@ -254,32 +303,55 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
             store_vec<T, 12>(L.c12 + (size_t)j * 12, lead);
           }
         }
+      }
+      if constexpr (SCHEME == KR_EULER) {
+        load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hv);
+        y = state_axpy(y, Pc.ds, k1);
+      } else {
+        T hn[HS], hm[HS];
+        load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hn);
+#pragma unroll
+        for (int c = 0; c < HS; ++c) hm[c] = T(0.5) * (hv[c] + hn[c]);
+        RodState<T> k2, k3, k4;
+        V3<T> v2, u2;
+        RodState<T> ya = state_axpy(y, Pc.ds * T(0.5), k1);
+        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k2, v2, u2);
+        ya = state_axpy(y, Pc.ds * T(0.5), k2);
+        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k3, v2, u2);
+        ya = state_axpy(y, Pc.ds, k3);
+        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hn, k4, v2, u2);
+        RodState<T> ksum = state_axpy(k1, T(2), k2);
+        ksum = state_axpy(ksum, T(2), k3);
+        ksum = state_axpy(ksum, T(1), k4);
+        y = state_axpy(y, Pc.ds / T(6), ksum);
+#pragma unroll
+        for (int c = 0; c < HS; ++c) hv[c] = hn[c];
+      }
+    };
+    if constexpr (NN) {
+      // with the MLP on every lane must reach the wave-wide matrix-core call: lanes past the end of
+      // their (shorter) interval keep running on the last grid point and simply do not commit
+      for (int t = 0; t < R.lmax; ++t) {
+        const bool live = t < R.len_i;
+        const int j = live ? R.s_i + t : R.s_i + R.len_i - 1;
+        const RodState<T> y_in = y;
+        if (storing || flush) point(std::true_type{}, j, live);  // wave-uniform choice
+        else point(std::false_type{}, j, true);
+        if (!live) y = y_in;
+      }
+    } else {
+      // every interval has sbase or sbase + 1 segments: the first sbase grid points need no predicate
+      if (storing || flush) {
+        for (int t = 0; t < R.sbase; ++t) point(std::true_type{}, R.s_i + t, true);
+        if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase, true);
+      } else {
         if constexpr (SCHEME == KR_EULER) {
-          load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hv);
-          y = state_axpy(y, Pc.ds, k1);
+#pragma unroll KR_MS_UNROLL
+          for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t, true);
         } else {
-          T hn[HS], hm[HS];
-          load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hn);
-#pragma unroll
-          for (int c = 0; c < HS; ++c) hm[c] = T(0.5) * (hv[c] + hn[c]);
-          RodState<T> k2, k3, k4;
-          V3<T> v2, u2;
-          RodState<T> ya = state_axpy(y, Pc.ds * T(0.5), k1);
-          eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k2, v2, u2);
-          ya = state_axpy(y, Pc.ds * T(0.5), k2);
-          eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k3, v2, u2);
-          ya = state_axpy(y, Pc.ds, k3);
-          eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hn, k4, v2, u2);
-          RodState<T> ksum = state_axpy(k1, T(2), k2);
-          ksum = state_axpy(ksum, T(2), k3);
-          ksum = state_axpy(ksum, T(1), k4);
-          y = state_axpy(y, Pc.ds / T(6), ksum);
-#pragma unroll
-          for (int c = 0; c < HS; ++c) hv[c] = hn[c];
+          for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t, true);
         }
-        if constexpr (NN) {
-          if (!live) y = y_in;
-        }
+        if (R.len_i > R.sbase) point(std::false_type{}, R.s_i + R.sbase, true);
       }
     }
     if (st && iv == MS_P - 1) {
@@ -300,81 +372,97 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     KR_STAMP_ADD(stamps.sweep, tq);
 #endif
 
-    // ---- hand the end states over (one LDS row per lane) ---------------------------
+    // ---- hand the end states over ----------------------------------------------------
+    // Es[lane] = end state E of the unperturbed lanes, forward-difference column
+    // (E - E_unperturbed) / step of the others: column c of A_g = dE_g/dY_g sits at Es[l0_g + 1 + c].
     {
       T er[19];
       state_to_rows(y, er);
+      const int l0own = iv == 0 ? 0 : 7 + 17 * (iv - 1);
+      if (col == 0 && !idle) {
 #pragma unroll
-      for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = er[r];
-      IH[lane] = col > 0 ? fast_rcp(hstep) : T(0);
+        for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = er[r];
+      }
+      wave_sync();
+      if (col > 0) {
+        const T ih = fast_rcp(hstep);
+        T e0[19];  // all loads first: the compiler cannot tell that they never alias the stores below
+#pragma unroll
+        for (int r = 0; r < 19; ++r) e0[r] = Es[l0own * MS_YP + r];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = (er[r] - e0[r]) * ih;
+      }
+      wave_sync();
+    }
+
+#ifdef KR_MS_STAMPS
+    unsigned long long ta = tq;
+    KR_STAMP_ADD(stamps.a1, ta);
+#endif
+    // ---- condensation -------------------------------------------------------------------
+    // dY_1 = c_0 + A_0 dG,  dY_{g+1} = c_g + A_g dY_g  with c_g = E_g - Y_{g+1}; written as
+    // dY_g = X_g [1; dG], X_g = [a_g | M_g] (19 x 7).  The p rows never feed back (no equation reads
+    // p), so the chain runs on rows 3..18 only: lane -> (row r, column pair kp) of X_g, 16 x 4 = 64
+    // lanes, 2 x 16 fused multiply-adds per stage, X_g handed on through a ping-pong LDS tile.
+    const int kp = lane & 3;
+    const int r = 3 + (lane >> 2);
+    T Xreg[MS_P - 1][2];  // this lane's pair of X_1 .. X_{P-1}
+    {
+      const T c0 = Es[0 * MS_YP + r] - Xs[1 * MS_YP + r];
+      const T da = Es[(2 * kp) * MS_YP + r];      // lanes 1..6 hold the columns of A_0 (lane 0: E_0, unused)
+      const T db = Es[(2 * kp + 1) * MS_YP + r];  // (lane 7 is E_1: masked below)
+      Xreg[0][0] = kp == 0 ? c0 : da;
+      Xreg[0][1] = kp == 3 ? T(0) : db;
+      store_pair(XB + r * 8 + 2 * kp, Xreg[0][0], Xreg[0][1]);
     }
     wave_sync();
-
-    // ---- condensation, row per lane ---------------------------------------------------
-    // lane -> (g, r): row r of interval g = 1..P-1.  The lane keeps row r of A_g = dE_g/dY_g
-    // (16 forward-difference columns; the p columns are the identity) in registers, receives
-    // row r of X_g = [a_g | M_g] (dY_g = a_g + M_g dG) and produces row r of
-    // X_{g+1} = [E_g - Y_{g+1} | 0] + A_g X_g, published through one 19x8 LDS tile.
-    const bool rowlane = lane < 19 * (MS_P - 1);
-    const int g = rowlane ? lane / 19 + 1 : 1;
-    const int r = rowlane ? lane - (g - 1) * 19 : 0;
-    const int l0 = 7 + 17 * (g - 1);  // unperturbed lane of interval g
-    const T e0 = Es[l0 * MS_YP + r];
-    T Arow[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Arow[c] = (Es[(l0 + 1 + c) * MS_YP + r] - e0) * IH[l0 + 1 + c];
-    const T cg = g < MS_P - 1 ? e0 - Xs[(g + 1) * MS_YP + r] : T(0);
-    T Xown[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) Xown[k] = T(0);
-    if (rowlane && g == 1) {  // X_1 = [E_0 - Y_1 | A_0]
-      const T e00 = Es[0 * MS_YP + r];
-      T x1[8];
-      x1[0] = e00 - Xs[1 * MS_YP + r];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) x1[1 + k] = (Es[(1 + k) * MS_YP + r] - e00) * IH[1 + k];
-      x1[7] = T(0);
-      store_vec<T, 8>(XB + r * 8, x1);
-    }
-    for (int stage = 1; stage < MS_P; ++stage) {
-      wave_sync();
-      T Xn[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) Xn[k] = T(0);
-      if (rowlane && g == stage) {
-        load_hist_vec<T, 8>(XB + r * 8, Xown);  // row r of X_g: needed for dY_g[r] below
-        Xn[0] = cg;
-        if (r < 3) {
-#pragma unroll
-          for (int k = 0; k < 7; ++k) Xn[k] += Xown[k];
-        }
+    for (int g = 1; g < MS_P; ++g) {
+      const T* xcur = XB + ((g - 1) & 1) * (MS_YP * 8);
+      T* xnext = XB + (g & 1) * (MS_YP * 8);
+      const int l0 = 7 + 17 * (g - 1);  // unperturbed lane of interval g
+      const T e0 = Es[l0 * MS_YP + r];
+      T n0 = T(0), n1 = T(0), n2 = T(0), n3 = T(0);
+      if (g < MS_P - 1) {
+        const T cg = e0 - Xs[(g + 1) * MS_YP + r];
+        n0 = kp == 0 ? cg : T(0);
+      }
+      {
+        // issue all 32 LDS reads of the stage back to back, then the arithmetic (left alone, the
+        // scheduler waits for every read before it issues the next one)
+        T av[16], xa[16], xb[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          T xr[8];
-          load_hist_vec<T, 8>(XB + (3 + c) * 8, xr);
-#pragma unroll
-          for (int k = 0; k < 7; ++k) Xn[k] = fma(Arow[c], xr[k], Xn[k]);
+          av[c] = Es[(l0 + 1 + c) * MS_YP + r];
+          load_pair(xcur + (3 + c) * 8 + 2 * kp, xa[c], xb[c]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+          n0 = fma(av[c], xa[c], n0);
+          n1 = fma(av[c], xb[c], n1);
+          n2 = fma(av[c + 1], xa[c + 1], n2);
+          n3 = fma(av[c + 1], xb[c + 1], n3);
+        }
+        n0 += n2;
+        n1 += n3;
+      }
+      if (g < MS_P - 1) {
+        Xreg[g][0] = n0;
+        Xreg[g][1] = n1;
+        store_pair(xnext + r * 8 + 2 * kp, n0, n1);
+      } else if (r >= 7 && r < 13) {
+        // tip rows: [n;m](E_{P-1} + A_{P-1} dY_{P-1}) = [F_tip; M_tip]  ->  row [rhs | T] of T dG = rhs
+        if (kp == 0) n0 = L.cold[CD_FTIP + (r - 7)] - e0 - n0;  // F_tip (3) and M_tip (3) are adjacent
+        store_pair(Tm + (r - 7) * 8 + 2 * kp, n0, n1);
       }
       wave_sync();
-      if (rowlane && g == stage) {
-        if (stage < MS_P - 1) {
-          store_vec<T, 8>(XB + r * 8, Xn);
-        } else if (r >= 7 && r < 13) {
-          // tip rows: [n;m](E_{P-1} + A_{P-1}(a + M dG)) = [F_tip; M_tip]  ->  T dG = rhs
-          const int rr = r - 7;
-          const T target = L.cold[CD_FTIP + rr];  // F_tip (3) and M_tip (3) are adjacent
-          T trow[8];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) trow[k] = Xn[1 + k];
-          trow[6] = target - e0 - (Xn[0] - cg);  // cg is zero for the last interval
-          trow[7] = T(0);
-          store_vec<T, 8>(Tm + rr * 8, trow);
-        }
-      }
     }
-    wave_sync();
 
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.a2, ta);
+#endif
     // ---- 6x6 solve, redundantly in every lane (registers only) -------------------------
     T d[6];
     {
@@ -384,35 +472,95 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
         T row[8];
         load_hist_vec<T, 8>(Tm + i * 8, row);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) a6[i][k] = row[k];
+        for (int k = 0; k < 6; ++k) a6[i][k] = row[1 + k];
+        a6[i][6] = row[0];
       }
       solve6(a6, d);
     }
 
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.a3, ta);
+#endif
     // ---- updates and convergence --------------------------------------------------------
-    // scaled update norm over every unknown (base wrench and interior states)
-    T dn = T(0);
-    bool finite = true;
-    T upd = T(0);
-    int ui = -1, ur = 0;
-    if (rowlane) {
-      ui = g; ur = r;
-      T s = Xown[0];
+    // rows 3..18 of dY_g: every lane of a quad ends up with the full dot product X_g[r] . [1; dG]
+    T updY[MS_P - 1];
+    {
+      const T dd0 = kp == 0 ? T(1) : kp == 1 ? d[1] : kp == 2 ? d[3] : d[5];
+      const T dd1 = kp == 0 ? d[0] : kp == 1 ? d[2] : kp == 2 ? d[4] : T(0);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s = fma(Xown[1 + k], d[k], s);
-      upd = s;
-    } else if (lane - 19 * (MS_P - 1) < 6) {
-      const int k = lane - 19 * (MS_P - 1);
-      ui = 0; ur = 7 + k;
-      upd = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : k == 3 ? d[3] : k == 4 ? d[4] : d[5];
+      for (int g = 1; g < MS_P; ++g) {
+        T s = fma(Xreg[g - 1][1], dd1, Xreg[g - 1][0] * dd0);
+        s += quad_xor<0xB1>(s);  // lanes ^1
+        s += quad_xor<0x4E>(s);  // lanes ^2
+        updY[g - 1] = s;
+      }
     }
-    if (ui >= 0) {
-      dn = fabs(upd) / fmax(fabs(Xs[ui * MS_YP + ur]), T(1));
-      finite = isfinite(upd);
+    // the p rows: dY_{g}[p] = sum_{i<g} (c_i[p] + A_i[p,:] dY_i[3:]), one term per lane (i, row)
+    T* dYb = XB;  // the chain is done with its tiles: [g][19] scratch for dY_1 .. dY_{P-2}
+    T* sp = Tm;   // [P-1][3] partial sums (the solve has consumed Tm)
+    if (kp == 0) {
+#pragma unroll
+      for (int g = 1; g < MS_P - 1; ++g) dYb[g * MS_YP + r] = updY[g - 1];
+    }
+    wave_sync();
+    const bool plane = lane < 3 * (MS_P - 1);
+    const int pi = plane ? lane / 3 : 0;     // term i = 0 .. P-2
+    const int prow = plane ? lane - 3 * pi : 0;
+    if (plane) {
+      const int l0 = pi == 0 ? 0 : 7 + 17 * (pi - 1);
+      T s = Es[l0 * MS_YP + prow] - Xs[(pi + 1) * MS_YP + prow];
+      // uniform trip count (A_0 has 6 columns: the rest is masked) so that the reads can be batched
+      T av[16], dv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const bool use = pi > 0 || c < 6;
+        av[c] = use ? Es[(l0 + 1 + c) * MS_YP + prow] : T(0);
+        dv[c] = pi > 0 ? dYb[pi * MS_YP + 3 + c] : T(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      T s2 = T(0);
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        const T da = pi > 0 ? dv[c] : (c < 6 ? d[c < 6 ? c : 0] : T(0));
+        const T db = pi > 0 ? dv[c + 1] : (c + 1 < 6 ? d[c + 1 < 6 ? c + 1 : 0] : T(0));
+        s = fma(av[c], da, s);
+        s2 = fma(av[c + 1], db, s2);
+      }
+      sp[pi * 3 + prow] = s + s2;
+    }
+    wave_sync();
+
+    // scaled update norm over every unknown (base wrench and interior states).  The norm only steers the
+    // iteration (stop test, contraction estimate), so it is formed in fp32 with the hardware reciprocal.
+    float dnf = 0.f;
+    T updP = T(0), updG = T(0), xsP = T(0), xsG = T(0), xsY[MS_P - 1];
+    const bool glane = lane >= WAVE - 6;  // six otherwise idle lanes own the base wrench
+    if (plane) {  // this lane owns Y_{pi+1}[prow]
+      xsP = Xs[(pi + 1) * MS_YP + prow];
+#pragma unroll
+      for (int i = 0; i < MS_P - 1; ++i) {
+        const T t = sp[i * 3 + prow];
+        updP += i <= pi ? t : T(0);
+      }
+      dnf = update_ratio(updP, xsP);
+    }
+    if (glane) {
+      const int k = lane - (WAVE - 6);
+      xsG = Xs[0 * MS_YP + 7 + k];
+      updG = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : k == 3 ? d[3] : k == 4 ? d[4] : d[5];
+      dnf = fmaxf(dnf, update_ratio(updG, xsG));
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dn = fmax(dn, __shfl_xor(dn, o, WAVE));
-    finite = __all(finite);
+    for (int g = 1; g < MS_P; ++g) {
+      xsY[g - 1] = T(0);
+      if (((g - 1) & 3) == kp) {  // one lane of the quad owns Y_g[r]
+        xsY[g - 1] = Xs[g * MS_YP + r];
+        dnf = fmaxf(dnf, update_ratio(updY[g - 1], xsY[g - 1]));
+      }
+    }
+    dnf = wave_max_nonneg(dnf);  // +inf if any update is not finite
+    const bool finite = dnf <= 3.0e38f;
+    const T dn = (T)dnf;
 
     bool done = false;
     if (!finite) {
@@ -423,7 +571,11 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       done = true;  // the state streamed out by this sweep is the accepted one
       status = KR_ST_CONVERGED;
     } else {
-      if (ui >= 0) Xs[ui * MS_YP + ur] += upd;
+      if (plane) Xs[(pi + 1) * MS_YP + prow] = xsP + updP;
+      if (glane) Xs[0 * MS_YP + 7 + (lane - (WAVE - 6))] = xsG + updG;
+#pragma unroll
+      for (int g = 1; g < MS_P; ++g)
+        if (((g - 1) & 3) == kp) Xs[g * MS_YP + r] = xsY[g - 1] + updY[g - 1];
       // stream the state out on the sweep that is expected to be accepted: Newton contracts
       // quadratically, |d_{k+1}| ~ kappa |d_k|^2 with kappa estimated from the last two updates
       if (predict_final<T>(dn, dn_prev, S.tol, S.tolA)) storing = true;
@@ -436,6 +588,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     }
     wave_sync();
 #ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.a4, ta);
     KR_STAMP_ADD(stamps.alg, tq);
     stamps.its += 1;
     if (it <= 4) stamps.dn[it - 1] = (double)dn;
@@ -665,7 +818,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   if (lane == 0 && A.dbg) {
     unsigned long long te;
     KR_STAMP(te);
-    unsigned long long* d = A.dbg + rod * 8;
+    unsigned long long* d = A.dbg + rod * 16;
+    d[8] = stamps.a1; d[9] = stamps.a2; d[10] = stamps.a3; d[11] = stamps.a4;
     d[0] = te - t_begin; d[1] = stamps.sweep; d[2] = stamps.alg; d[3] = stamps.prep; d[4] = (unsigned long long)stamps.its;
     for (int k = 0; k < 3; ++k) d[5 + k] = (unsigned long long)__double_as_longlong(stamps.dn[k]);
   }

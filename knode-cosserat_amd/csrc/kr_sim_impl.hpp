@@ -181,30 +181,36 @@ template <typename T>
 __device__ __forceinline__ bool predict_final(T dn, T dn_prev, T tol, T tolA) {
   if (dn <= tolA) return true;
   if (!(dn_prev > T(0)) || !(dn < dn_prev)) return false;
-  T kappa = dn / (dn_prev * dn_prev);
+  T kappa = dn * fast_rcp(dn_prev * dn_prev);  // an overflowing or NaN ratio ends up clamped below
   kappa = fmin(fmax(kappa, T(1e-3)), T(1));
   return T(4) * kappa * dn * dn <= tol;
 }
 
-// 6x6 solve, Gaussian elimination with partial pivoting on static indices.
+// 6x6 solve, Gaussian elimination with partial pivoting on static indices.  The row exchange is a real
+// branch, not a pair of selects per element: pivots rarely move (the tip-vs-base Jacobian is close to
+// block triangular with a unit diagonal), and where all lanes hold the same system the branch is uniform.
 template <typename T>
 __device__ __forceinline__ void solve6(T (&a)[6][7], T (&x)[6]) {
+  T inv[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
 #pragma unroll
     for (int i = k + 1; i < 6; ++i) {
-      const bool sw = fabs(a[i][k]) > fabs(a[k][k]);
+      if (__builtin_expect(fabs(a[i][k]) > fabs(a[k][k]), 0)) {
 #pragma unroll
-      for (int c = k; c < 7; ++c) {
-        const T t = a[k][c];
-        a[k][c] = sw ? a[i][c] : t;
-        a[i][c] = sw ? t : a[i][c];
+        for (int c = k; c < 7; ++c) {
+          const T t = a[k][c];
+          a[k][c] = a[i][c];
+          a[i][c] = t;
+        }
       }
     }
-    const T inv = T(1) / a[k][k];
+    // reciprocal of the pivot by the hardware estimate + Newton steps (full precision for a normal
+    // pivot; a zero pivot gives inf/nan, which the callers report as KR_ST_NONFINITE)
+    inv[k] = fast_rcp(a[k][k]);
 #pragma unroll
     for (int i = k + 1; i < 6; ++i) {
-      const T f = a[i][k] * inv;
+      const T f = a[i][k] * inv[k];
 #pragma unroll
       for (int c = k + 1; c < 7; ++c) a[i][c] = fma(-f, a[k][c], a[i][c]);
     }
@@ -214,7 +220,7 @@ __device__ __forceinline__ void solve6(T (&a)[6][7], T (&x)[6]) {
     T s = a[k][6];
 #pragma unroll
     for (int c = k + 1; c < 6; ++c) s = fma(-a[k][c], x[c], s);
-    x[k] = s / a[k][k];
+    x[k] = s * inv[k];
   }
 }
 

@@ -12,7 +12,7 @@ B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 100, 120
 dev = "cuda:0"; dt = torch.float64
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
 h = r._native(); h.set_option("ms_mode", 1); h.set_option("persistent", 1)
-dbg = torch.zeros((B, 8), dtype=torch.int64, device=dev)
+dbg = torch.zeros((B, 16), dtype=torch.int64, device=dev)
 kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
 ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 1235), device=dev).contiguous()
 for pred in (0, 2):
@@ -27,6 +27,7 @@ for pred in (0, 2):
     print(f"pred={pred}: wall {el/T*1e6:.1f} us/step; s_memtime ticks per step: total mean {tot.mean()/T:.0f} max {tot.max()/T:.0f} | "
           f"sweep {sw.mean()/T:.0f} alg {al.mean()/T:.0f} prep {pr.mean()/T:.0f} | its/step mean {its.mean()/T:.2f} max {its.max()/T:.2f} | "
           f"per-iteration sweep {sw.sum()/its.sum():.0f} alg {al.sum()/its.sum():.0f} ticks; tick rate {tot.max()/el/1e6:.1f} MHz")
+    print(f"   algebra per iteration: hand-over {d[:,8].sum()/its.sum():.0f} chain {d[:,9].sum()/its.sum():.0f} solve {d[:,10].sum()/its.sum():.0f} update {d[:,11].sum()/its.sum():.0f}")
     dn = dbg[:, 5:8].cpu().numpy().view(np.float64)
     its_rod = its / T
     order = np.argsort(-its_rod)
