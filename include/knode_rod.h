@@ -119,14 +119,17 @@ int kr_destroy(kr_handle* h);
  *   "ms_batch_limit" auto mode uses it when B <= limit (default 2048)
  *   "persistent"     1 (default) / 0: kr_simulate_batch runs all steps in one launch when the
  *                    multiple-shooting kernel applies
- *   "predictor"      0..2: highest order of the time extrapolation kr_simulate_batch uses for
- *                    the initial guess of each step (default 2; 0 = the reference's warm start) */
+ *   "predictor"      0..7: highest order of the time extrapolation kr_simulate_batch uses for
+ *                    the initial guess of each step (default 7; 0 = the reference's warm start).
+ *                    The persistent kernel picks, rod by rod and step by step, the order <= this
+ *                    that would have predicted the step just solved best; one launch per step
+ *                    uses min(this, 2) */
 int kr_set_option(kr_handle* h, const char* name, int value);
 /* reads an option back; additionally "last_sim_path": what the last kr_simulate_batch did -
  * 0 one single-shooting launch per step, 1 one multiple-shooting launch per step, 2 one
  * persistent launch for all steps */
 int kr_get_option(kr_handle* h, const char* name, int* value);
-/* Diagnostic builds only (-DKR_MS_STAMPS): device buffer [B][8] of uint64 that the persistent
+/* Diagnostic builds only (-DKR_MS_STAMPS): device buffer [B][24] of uint64 that the persistent
  * kernel fills with per-rod cycle counters {total, sweep, algebra, prologue, iterations}. */
 int kr_debug_buffer(kr_handle* h, void* dev_ptr);
 /* CosseratRod.compute_intermediate_terms, cosserat_ode.py:58-78 */

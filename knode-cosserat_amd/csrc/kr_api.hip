@@ -185,7 +185,7 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
                           T_steps * 4, tol, maxit);
     // time extrapolation of the initial guess from the states already computed (order <= h->predictor)
     int order = t == 0 ? (prev_init ? 1 : 0) : (t == 1 ? (prev_init ? 2 : 1) : 2);
-    if (order > h->predictor) order = h->predictor;
+    if (order > h->predictor) order = h->predictor;  // (orders 3..5: persistent kernel only)
     if (order == 2) a.prev2 = t == 1 ? (const T*)prev_init : base + (ring ? (t + 1) % 3 : t - 2) * slot;
     a.pred_order = order;
     if (tip) { a.tip = (T*)tip + t * 3; a.tip_stride = T_steps * 3; }
@@ -309,7 +309,7 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
   } else if (n == "mfma_mlp") {
     h->mfma_mlp = value ? 1 : 0;  // takes effect at the next kr_set_mlp
   } else if (n == "predictor") {
-    if (value < 0 || value > 2) { set_error("predictor must be 0, 1 or 2"); return KR_E_ARG; }
+    if (value < 0 || value > 7) { set_error("predictor must be 0 .. 7"); return KR_E_ARG; }
     h->predictor = value;
   } else {
     set_error("unknown option " + n);

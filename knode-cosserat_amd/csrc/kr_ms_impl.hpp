@@ -101,6 +101,23 @@ __device__ __forceinline__ T extrapolate(int order, T g0, T g1, T g2) {
   return T(3) * (g0 - g1) + g2;
 }
 
+constexpr int MS_HLEV = 8;  // time levels of the unknowns the persistent kernel keeps (predictor order <= 7)
+// polynomial extrapolation one step ahead from the newest `order + 1` levels h[0] (newest) .. h[order]:
+// sum_k (-1)^k C(order+1, k+1) h[k]
+template <typename T>
+__device__ __forceinline__ T extrapolate_n(int order, const T (&h)[MS_HLEV]) {
+  switch (order) {
+    case 0: return h[0];
+    case 1: return T(2) * h[0] - h[1];
+    case 2: return T(3) * (h[0] - h[1]) + h[2];
+    case 3: return T(4) * (h[0] + h[2]) - T(6) * h[1] - h[3];
+    case 4: return T(5) * (h[0] - h[3]) + T(10) * (h[2] - h[1]) + h[4];
+    case 5: return T(6) * (h[0] + h[4]) - T(15) * (h[1] + h[3]) + T(20) * h[2] - h[5];
+    case 6: return T(7) * (h[0] - h[5]) + T(21) * (h[4] - h[1]) + T(35) * (h[2] - h[3]) + h[6];
+    default: return T(8) * (h[0] + h[6]) - T(28) * (h[1] + h[5]) + T(56) * (h[2] + h[4]) - T(70) * h[3] - h[7];
+  }
+}
+
 enum : int {
   CD_P0 = 0, CD_H0 = 3, CD_Q0 = 7, CD_W0 = 10, CD_FTIP = 13, CD_MTIP = 16, CD_TDIRS = 19, CD_RHOAG = 31,
   CD_KSEI = 34, CD_KSEV = 43, CD_BSE = 46, CD_KBTI = 55, CD_BBT = 64, CD_SIZE = 76
@@ -113,14 +130,14 @@ __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = fa
   size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);
   if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
   size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + alg;
-  if (persist) n += (size_t)N * 12 + 3 * MS_P * MS_YP;
+  if (persist) n += (size_t)N * 12;
   return (n + 3) & ~size_t(3);
 }
 
 #ifdef KR_MS_STAMPS
 #define KR_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); (var) = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define KR_STAMP_ADD(acc, t0) do { unsigned long long _t; KR_STAMP(_t); (acc) += _t - (t0); (t0) = _t; } while (0)
-struct MsStamps { unsigned long long sweep = 0, alg = 0, prep = 0, total = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0; int its = 0; double dn[4] = {0, 0, 0, 0}; };
+struct MsStamps { unsigned long long sweep = 0, alg = 0, prep = 0, total = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, osum = 0, retries = 0; int its = 0, olast = 0; float em[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double dn[4] = {0, 0, 0, 0}; };
 #else
 #define KR_STAMP(var) do { } while (0)
 #define KR_STAMP_ADD(acc, t0) do { } while (0)
@@ -242,6 +259,9 @@ struct MsSolveArgs {
   V3<T> vlast, ulast;
   T tol, tolA, fd_eps;
   int maxit;
+  // contraction constant |d_{k+1}| / |d_k|^2 seen where an earlier solve of this rod first got below the
+  // tolerance (0: unknown).  In: used to decide which sweep streams the state out; out: refreshed.
+  T kappa;
 };
 
 // Newton iteration on (G, Y_1..Y_{P-1}) for one rod = one wavefront.  On entry L.hist holds the
@@ -249,7 +269,7 @@ struct MsSolveArgs {
 // = sweeps used.  On exit L.Xs holds the accepted unknowns.
 template <typename T, bool DIAG, int SCHEME, int HS, bool PERSIST, bool NN>
 __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>& M, const MsLds<T>& L, const MsRole& R,
-                                         int lane, const SweepCtx<T, HS>& C, const MsSolveArgs<T>& S, int& it,
+                                         int lane, const SweepCtx<T, HS>& C, MsSolveArgs<T>& S, int& it,
                                          MsStamps& stamps) {
   const int N = Pc.N;
 #ifdef KR_MS_STAMPS
@@ -263,6 +283,8 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
   int status = KR_ST_MAXIT;
   it = 0;
   T dn_prev = T(-1);  // update norm of the previous iteration (contraction estimate)
+  const T kappa_in = S.kappa;
+  bool below = false;  // an update at or below the tolerance has been seen
 
   while (true) {
     // ---- start state of this lane ------------------------------------------
@@ -562,6 +584,16 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     const bool finite = dnf <= 3.0e38f;
     const T dn = (T)dnf;
 
+    if (finite && !below && dn <= S.tol) {
+      below = true;
+      // (the measured norm bottoms out at rounding level: bound it from below so that one lucky
+      // step does not make the estimate wildly optimistic)
+      if (dn_prev > T(0)) {
+        const T floor_dn = T(64) * (sizeof(T) == 8 ? T(2.2e-16) : T(1.2e-7));
+        const T k = fmax(dn, floor_dn) * fast_rcp(dn_prev * dn_prev);
+        S.kappa = fmin(fmax(k, T(1e-4)), T(1));
+      }
+    }
     bool done = false;
     if (!finite) {
       done = true;
@@ -579,6 +611,9 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       // stream the state out on the sweep that is expected to be accepted: Newton contracts
       // quadratically, |d_{k+1}| ~ kappa |d_k|^2 with kappa estimated from the last two updates
       if (predict_final<T>(dn, dn_prev, S.tol, S.tolA)) storing = true;
+      // the estimate from inside one solve is pessimistic (the first update mostly closes the interface
+      // jumps, which is a linear problem); the constant remembered from the previous time step is not
+      if (kappa_in > T(0) && T(4) * kappa_in * dn * dn <= S.tol) storing = true;
       dn_prev = dn;
       if (it >= S.maxit) {
         done = true;
@@ -677,6 +712,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   S.out_rod = A.next + rod * rod_elems;
   S.tip = A.tip ? A.tip + rod * A.tip_stride : nullptr;
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  S.kappa = T(0);
   wave_sync();
   int it;
   MsStamps stamps;
@@ -703,7 +739,6 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   if (rod >= A.B) return;  // whole wavefront; there is no workgroup barrier in this kernel
   const size_t rod_elems = (size_t)N * KR_SLOTS;
   const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, true), N, true);
-  T* Yh = L.c12 + (size_t)N * 12;  // [3][P][MS_YP] interval-start states of the last three time levels
   const MsRole R = ms_role(lane, N);
   ms_cold_fill<T>(Pc, L.cold, lane);
   wave_sync();
@@ -727,13 +762,20 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
       for (int c = 0; c < 12; ++c) regP[q][c] = T(0);
     }
   }
-  // interval-start states of states[0] and of the state before it (for the extrapolation)
-  for (int e = lane; e < MS_P * 19; e += WAVE) {
-    const int i = e / 19, r = e - i * 19;
+  // time levels of the unknowns (interval-start states; extrapolated to start Newton), in registers:
+  // lane l keeps elements l and 64 + l of the MS_P x 19 vector
+  static_assert(MS_YP == 19, "Xs is indexed as one flat vector below");
+  constexpr int MS_NE = MS_P * 19;
+  constexpr int MS_EPL = (MS_NE + WAVE - 1) / WAVE;
+  T Hx[MS_EPL][MS_HLEV];
+#pragma unroll
+  for (int q = 0; q < MS_EPL; ++q) {
+    const int e = lane + q * WAVE;
+    const int i = e < MS_NE ? e / 19 : 0, r = e < MS_NE ? e - i * 19 : 0;
     const size_t off = (size_t)ms_interval_start(i, R.sbase, R.srem) * KR_SLOTS + ms_slot_of_yrow(r);
-    Yh[(0 * MS_P + i) * MS_YP + r] = s0[off];
-    Yh[(1 * MS_P + i) * MS_YP + r] = sp[off];
-    Yh[(2 * MS_P + i) * MS_YP + r] = sp[off];
+    Hx[q][0] = s0[off];
+#pragma unroll
+    for (int k = 1; k < MS_HLEV; ++k) Hx[q][k] = sp[off];
   }
   MsSolveArgs<T> S;
   {
@@ -742,7 +784,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     S.ulast = {cl[SL_U], cl[SL_U + 1], cl[SL_U + 2]};
   }
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  S.kappa = T(0);
   int avail = A.prev_init ? 1 : 0;  // time levels behind states[0] that carry information
+  int next_order = avail < A.predictor ? avail : A.predictor;  // extrapolation order of the coming step
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];
@@ -771,20 +815,6 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
         for (int c = 0; c < 12; ++c) regP[q][c] = cv[c];
       }
     }
-    // ---- initial guess ----------------------------------------------------------
-    int order = avail < A.predictor ? avail : A.predictor;
-    for (int e = lane; e < MS_P * 19; e += WAVE) {
-      const int i = e / 19, r = e - i * 19;
-      T g = extrapolate<T>(order, Yh[(0 * MS_P + i) * MS_YP + r], Yh[(1 * MS_P + i) * MS_YP + r],
-                           Yh[(2 * MS_P + i) * MS_YP + r]);
-      if (i == 0) {
-        T bc;
-        if (ms_base_bc(L.cold, r, bc)) g = bc;
-      }
-      L.Xs[i * MS_YP + r] = g;
-    }
-    wave_sync();
-    if (order <= 0 && lane < 6) L.Xs[0 * MS_YP + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
     SweepCtx<T, HS> C;
     ms_ctx_init<T, HS>(L.cold, L.hist, tens, C);
     if (t + 1 < A.T_steps) {  // next step's tensions: issued now, consumed after this step's solve
@@ -794,23 +824,88 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     const int64_t inx = A.ring ? (t + 1) % 3 : t + 1;
     S.out_rod = A.states + inx * A.slot_elems + rod * rod_elems;
     S.tip = A.tip ? A.tip + (rod * A.T_steps + t) * 3 : nullptr;
-    wave_sync();
+    // ---- initial guess and solve ---------------------------------------------------
+    int order = next_order;
+    int status, it;
+    while (true) {
+#pragma unroll
+      for (int q = 0; q < MS_EPL; ++q) {
+        const int e = lane + q * WAVE;
+        if (e < MS_NE) {
+          const int i = e / 19, r = e - i * 19;
+          T g = extrapolate_n<T>(order, Hx[q]);
+          if (i == 0) {
+            T bc;
+            if (ms_base_bc(L.cold, r, bc)) g = bc;
+          }
+          L.Xs[i * MS_YP + r] = g;
+        }
+      }
+      wave_sync();
+      if (order <= 0 && lane < 6) L.Xs[0 * MS_YP + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
+      wave_sync();
 #ifdef KR_MS_STAMPS
-    KR_STAMP_ADD(stamps.prep, tp);
+      KR_STAMP_ADD(stamps.prep, tp);
 #endif
-    int it;
-    const int status = ms_newton<T, DIAG, SCHEME, HS, true, false>(Pc, MlpDev<T>{}, L, R, lane, C, S, it, stamps);
+      status = ms_newton<T, DIAG, SCHEME, HS, true, false>(Pc, MlpDev<T>{}, L, R, lane, C, S, it, stamps);
+      if (status == KR_ST_CONVERGED || order == 0) break;
+      order = 0;  // the extrapolated start did not converge: redo the step from the reference's warm start
+#ifdef KR_MS_STAMPS
+      stamps.retries += 1;
+      KR_STAMP(tp);
+#endif
+    }
     if (lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
     // ---- shift the time levels of the unknowns ------------------------------------
-    for (int e = lane; e < MS_P * 19; e += WAVE) {
-      const int i = e / 19, r = e - i * 19;
-      const T y1 = Yh[(1 * MS_P + i) * MS_YP + r], y0 = Yh[(0 * MS_P + i) * MS_YP + r];
-      Yh[(2 * MS_P + i) * MS_YP + r] = y1;
-      Yh[(1 * MS_P + i) * MS_YP + r] = y0;
-      Yh[(0 * MS_P + i) * MS_YP + r] = L.Xs[i * MS_YP + r];
+    // ---- extrapolation order of the next step: the one that would have predicted this step best ----
+    // (smooth inputs climb to the highest order; after a jump in the controls the low orders win
+    // until the jump has left the stencil; fresh random controls every step stay at order 0, which
+    // is the reference's warm start, knode.py:89)
+    {
+      float err[MS_HLEV];
+#pragma unroll
+      for (int p = 0; p < MS_HLEV; ++p) err[p] = 0.f;
+#pragma unroll
+      for (int q = 0; q < MS_EPL; ++q) {
+        const int e = lane + q * WAVE;
+        if (e < MS_NE) {
+          const T x = L.Xs[e];
+#pragma unroll
+          for (int p = 0; p < MS_HLEV; ++p) err[p] = fmaxf(err[p], update_ratio(x - extrapolate_n<T>(p, Hx[q]), x));
+        }
+      }
+      const int pmax = avail < A.predictor ? avail : A.predictor;  // orders the history supported
+      float em[MS_HLEV];
+#pragma unroll
+      for (int p = 0; p < MS_HLEV; ++p) em[p] = wave_max_nonneg(err[p]);
+      // best order, at most two above the one just used (chance hits on rough data - where the errors
+      // grow with the order - do not add up to a high order; on smooth data the errors of neighbouring
+      // orders can tie, every second one gains)
+      int nxt = 0;
+      float eb = em[0];
+#pragma unroll
+      for (int p = 1; p < MS_HLEV; ++p)
+        if (p <= pmax && p <= order + 2 && em[p] < eb) { eb = em[p]; nxt = p; }
+      if (nxt == avail && avail + 1 < MS_HLEV && avail + 1 <= A.predictor && nxt >= order) nxt = avail + 1;  // history still growing
+      next_order = nxt;
+#ifdef KR_MS_STAMPS
+      stamps.osum += (unsigned long long)order; stamps.olast = order;
+      for (int p = 0; p < MS_HLEV; ++p) stamps.em[p] = em[p];
+#endif
+      if (status != KR_ST_CONVERGED) {  // start over from the plain warm start
+        next_order = 0;
+        avail = -1;  // becomes 0 below
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MS_EPL; ++q) {
+      const int e = lane + q * WAVE;
+#pragma unroll
+      for (int k = MS_HLEV - 1; k > 0; --k) Hx[q][k] = Hx[q][k - 1];
+      if (e < MS_NE) Hx[q][0] = L.Xs[e];  // MS_YP == 19: Xs is the same flat vector
     }
     if (lane < 6) Gguess = L.Xs[0 * MS_YP + 7 + lane];
-    if (avail < 2) ++avail;
+    if (avail < MS_HLEV - 1) ++avail;
     wave_sync();
   }
   if (lane < 6) A.G[rod * 6 + lane] = Gguess;
@@ -818,8 +913,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   if (lane == 0 && A.dbg) {
     unsigned long long te;
     KR_STAMP(te);
-    unsigned long long* d = A.dbg + rod * 16;
+    unsigned long long* d = A.dbg + rod * 24;
+    for (int p = 0; p < 8; ++p) d[16 + p] = (unsigned long long)__double_as_longlong((double)stamps.em[p]);
     d[8] = stamps.a1; d[9] = stamps.a2; d[10] = stamps.a3; d[11] = stamps.a4;
+    d[12] = stamps.osum; d[13] = (unsigned long long)stamps.olast; d[14] = stamps.retries;
     d[0] = te - t_begin; d[1] = stamps.sweep; d[2] = stamps.alg; d[3] = stamps.prep; d[4] = (unsigned long long)stamps.its;
     for (int k = 0; k < 3; ++k) d[5 + k] = (unsigned long long)__double_as_longlong(stamps.dn[k]);
   }

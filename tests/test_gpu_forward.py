@@ -340,6 +340,48 @@ def test_full_size_properties(torch_cuda, shooting_mode):
     assert float(states[T][..., 25:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kind", ["sine_fast", "step", "random"])
+def test_adaptive_predictor_on_rough_inputs(torch_cuda, kind):
+    """The persistent kernel extrapolates the unknowns in time with an order (<= 7) it picks per rod and
+    step.  On inputs that are not smooth (a jump; fresh random tensions every step, physics_controls.py:
+    22-30) it has to fall back to low orders: every step must still converge, to the same states as the
+    reference's plain warm start (predictor 0, one launch per step)."""
+    torch = torch_cuda
+    r = make_robot(None, 40)
+    h = r._native()
+    B, T = 16, 90
+    rng = np.random.default_rng(5)
+    i = np.arange(1, T + 1)[None, :, None]
+    k = np.arange(4)[None, None, :]
+    if kind == "sine_fast":
+        per = rng.uniform(0.4, 0.6, size=(B, 1, 1))
+        ctl = 6.0 + np.sin(2 * np.pi * i * r.del_t / per + k * np.pi / 2)
+    elif kind == "step":
+        ctl = np.full((B, T, 4), 5.0)
+        jump = rng.uniform(0.5, 2.0, size=(B, 1))
+        ctl[:, 30:, 0] += jump
+        ctl[:, 30:, 3] += jump
+        ctl[:, 60:, 1] += 0.5 * jump
+    else:
+        ctl = 5.0 + 5.0 * rng.uniform(size=(B, T, 4))
+    dev = "cuda:0"
+    ctl_t = torch.as_tensor(ctl, device=dev).contiguous()
+    outs = []
+    for pred, persistent in ((7, 1), (0, 0)):
+        h.set_option("predictor", pred)
+        h.set_option("persistent", persistent)
+        st = h.new_state(B, torch.float64, n_slots=T + 1)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=torch.float64, device=dev)
+        status = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+        h.simulate(ctl_t, st, G, status=status)
+        torch.cuda.synchronize()
+        assert int((status != 0).sum()) == 0
+        outs.append(st[..., :25].cpu().numpy())
+    for t in (1, 29, 31, 35, 61, T):  # both solves stop at |update| <= 1e-8: agreement at that level
+        assert rel_l2(outs[0][t], outs[1][t]) < 1e-7
+
+
 def test_error_paths(torch_cuda):
     torch = torch_cuda
     import krod_native as kn

@@ -12,10 +12,10 @@ B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 100, 120
 dev = "cuda:0"; dt = torch.float64
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
 h = r._native(); h.set_option("ms_mode", 1); h.set_option("persistent", 1)
-dbg = torch.zeros((B, 16), dtype=torch.int64, device=dev)
+dbg = torch.zeros((B, 24), dtype=torch.int64, device=dev)
 kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
 ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 1235), device=dev).contiguous()
-for pred in (0, 2):
+for pred in (7,):
     h.set_option("predictor", pred)
     st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
     h.simulate(ctl[:, :21].contiguous(), st, G, ring=True)
@@ -32,7 +32,10 @@ for pred in (0, 2):
     its_rod = its / T
     order = np.argsort(-its_rod)
     print("   worst rods (its/step, last step dn1 dn2 dn3):")
-    for b in order[:6]: print(f"     rod {b}: {its_rod[b]:.2f}  {dn[b,0]:.1e} {dn[b,1]:.1e} {dn[b,2]:.1e}")
+    for b in order[:6]: print(f"     rod {b}: {its_rod[b]:.2f}  {dn[b,0]:.1e} {dn[b,1]:.1e} {dn[b,2]:.1e}  mean order {d[b,12]/T:.2f} last {int(d[b,13])} retries {int(d[b,14])}")
+    em = dbg[:, 16:24].cpu().numpy().view(np.float64)
+    for b in order[:4]: print("     rod", b, "prediction errors by order (last step):", " ".join(f"{x:.1e}" for x in em[b]))
+    print("   order histogram (last step):", np.bincount(d[:,13].astype(int), minlength=8), " retries total", int(d[:,14].sum()))
     print("   best rods:")
     for b in order[-3:]: print(f"     rod {b}: {its_rod[b]:.2f}  {dn[b,0]:.1e} {dn[b,1]:.1e} {dn[b,2]:.1e}")
     print("   dn1 quantiles", np.quantile(dn[:,0],[0.5,0.9,0.99,1.0]), " dn2", np.quantile(dn[:,1],[0.5,0.9,0.99,1.0]), " dn3", np.quantile(dn[:,2],[0.5,0.9,0.99,1.0]))
