@@ -126,38 +126,52 @@ __device__ __forceinline__ float fast_rcp(float x) {
   return r;
 }
 
-// Un-normalised quaternion rotation, cosserat_ode.py:133-137, as
-// R = I + s*M with M quadratic in h.  Holds M and s separately.
+// Un-normalised quaternion rotation, cosserat_ode.py:133-137: R = I + (2 / h.h) M(h), entries formed
+// directly from (s b, s c, s d) with s = 2 / h.h: 31 operations to build, 9 per product (the sweep applies
+// it five times per grid point, and the sweeps are bound by the fp64 instruction count).
 template <typename T>
 struct Rot {
-  T m00, m01, m02, m10, m11, m12, m20, m21, m22, s;
+  T r00, r01, r02, r10, r11, r12, r20, r21, r22;
+  // R x + y
+  __device__ __forceinline__ V3<T> apply_add(V3<T> x, V3<T> y) const {
+    return {fma(r00, x.x, fma(r01, x.y, fma(r02, x.z, y.x))), fma(r10, x.x, fma(r11, x.y, fma(r12, x.z, y.y))),
+            fma(r20, x.x, fma(r21, x.y, fma(r22, x.z, y.z)))};
+  }
   __device__ __forceinline__ V3<T> apply(V3<T> x) const {  // R x
-    V3<T> t{m00 * x.x + m01 * x.y + m02 * x.z, m10 * x.x + m11 * x.y + m12 * x.z,
-            m20 * x.x + m21 * x.y + m22 * x.z};
-    return axpy(s, t, x);
+    return {fma(r00, x.x, fma(r01, x.y, r02 * x.z)), fma(r10, x.x, fma(r11, x.y, r12 * x.z)),
+            fma(r20, x.x, fma(r21, x.y, r22 * x.z))};
   }
   __device__ __forceinline__ V3<T> applyT(V3<T> x) const {  // R^T x
-    V3<T> t{m00 * x.x + m10 * x.y + m20 * x.z, m01 * x.x + m11 * x.y + m21 * x.z,
-            m02 * x.x + m12 * x.y + m22 * x.z};
-    return axpy(s, t, x);
+    return {fma(r00, x.x, fma(r10, x.y, r20 * x.z)), fma(r01, x.x, fma(r11, x.y, r21 * x.z)),
+            fma(r02, x.x, fma(r12, x.y, r22 * x.z))};
   }
 };
 
 template <typename T>
 __device__ __forceinline__ Rot<T> make_rot(T a, T b, T c, T d) {
   Rot<T> R;
-  const T bb = b * b, cc = c * c, dd = d * d;
-  R.s = T(2) * fast_rcp(a * a + bb + cc + dd);
-  R.m00 = -cc - dd;
-  R.m01 = b * c - d * a;
-  R.m02 = b * d + c * a;
-  R.m10 = b * c + d * a;
-  R.m11 = -bb - dd;
-  R.m12 = c * d - b * a;
-  R.m20 = b * d - c * a;
-  R.m21 = c * d + b * a;
-  R.m22 = -bb - cc;
+  const T s = T(2) * fast_rcp(fma(a, a, fma(b, b, fma(c, c, d * d))));
+  const T sb = s * b, sc = s * c, sd = s * d;
+  R.r00 = fma(-sc, c, fma(-sd, d, T(1)));
+  R.r01 = fma(sb, c, -sd * a);
+  R.r02 = fma(sb, d, sc * a);
+  R.r10 = fma(sb, c, sd * a);
+  R.r11 = fma(-sb, b, fma(-sd, d, T(1)));
+  R.r12 = fma(sc, d, -sb * a);
+  R.r20 = fma(sb, d, -sc * a);
+  R.r21 = fma(sc, d, sb * a);
+  R.r22 = fma(-sb, b, fma(-sc, c, T(1)));
   return R;
+}
+
+// a x b + c and c - a x b with the products fused
+template <typename T>
+__device__ __forceinline__ V3<T> cross_add(V3<T> a, V3<T> b, V3<T> c) {
+  return {fma(a.y, b.z, fma(-a.z, b.y, c.x)), fma(a.z, b.x, fma(-a.x, b.z, c.y)), fma(a.x, b.y, fma(-a.y, b.x, c.z))};
+}
+template <typename T>
+__device__ __forceinline__ V3<T> cross_sub(V3<T> c, V3<T> a, V3<T> b) {
+  return {fma(-a.y, b.z, fma(a.z, b.y, c.x)), fma(-a.z, b.x, fma(a.x, b.z, c.y)), fma(-a.x, b.y, fma(a.y, b.x, c.z))};
 }
 
 // ys (same struct as the state) and z = [v u]; fconst = rhoA*g + tendon force.
@@ -181,18 +195,20 @@ __device__ __forceinline__ void ode_eval(const RodConst<T>& P, const RodState<T>
   // rod state derivatives, cosserat_ode.py:151-158
   ys.p = R.apply(v);
   V3<T> drag{P.C[0] * y.q.x * fabs(y.q.x), P.C[1] * y.q.y * fabs(y.q.y), P.C[2] * y.q.z * fabs(y.q.z)};
-  V3<T> fin = axpy(P.rhoA, cross(y.w, y.q) + qt, drag);
-  ys.n = R.apply(fin) - fconst;
+  V3<T> fin = axpy(P.rhoA, cross_add(y.w, y.q, qt), drag);
+  ys.n = R.apply_add(fin, V3<T>{-fconst.x, -fconst.y, -fconst.z});
   V3<T> Jw = mv<T, DIAG>(P.rhoJ, y.w);
-  ys.m = R.apply(mv_add<T, DIAG>(P.rhoJ, wt, cross(y.w, Jw))) - cross(ys.p, y.n);
-  ys.q = vt - cross(u, y.q) + cross(y.w, v);
-  ys.w = ut - cross(u, y.w);
+  const V3<T> pxn = cross(ys.p, y.n);
+  ys.m = R.apply_add(mv_add<T, DIAG>(P.rhoJ, wt, cross(y.w, Jw)), V3<T>{-pxn.x, -pxn.y, -pxn.z});
+  ys.q = cross_add(y.w, v, cross_sub(vt, u, y.q));
+  ys.w = cross_sub(ut, u, y.w);
 
   // quaternion derivative, cosserat_ode.py:161-165
-  ys.h0 = T(0.5) * (-u.x * y.h1 - u.y * y.h2 - u.z * y.h3);
-  ys.h1 = T(0.5) * (u.x * y.h0 + u.z * y.h2 - u.y * y.h3);
-  ys.h2 = T(0.5) * (u.y * y.h0 - u.z * y.h1 + u.x * y.h3);
-  ys.h3 = T(0.5) * (u.z * y.h0 + u.y * y.h1 - u.x * y.h2);
+  const V3<T> hu{T(0.5) * u.x, T(0.5) * u.y, T(0.5) * u.z};
+  ys.h0 = fma(-hu.x, y.h1, fma(-hu.y, y.h2, -hu.z * y.h3));
+  ys.h1 = fma(hu.x, y.h0, fma(hu.z, y.h2, -hu.y * y.h3));
+  ys.h2 = fma(hu.y, y.h0, fma(-hu.z, y.h1, hu.x * y.h3));
+  ys.h3 = fma(hu.z, y.h0, fma(hu.y, y.h1, -hu.x * y.h2));
 }
 
 // y + a*k  (Euler update / RK stage argument)
