@@ -204,6 +204,27 @@ class CosseratRodTorch:
         st["_handle"] = None
         return st
 
+    def __setstate__(self, st):
+        """Also adopts the attribute dictionary of a robot pickled by the reference's class of the same
+        name (physics_train.py:284-288): same attribute names, no native handle."""
+        self.__dict__.update(st)
+        self._handle = None
+        self.__dict__.setdefault("nn_input_history", False)
+        self.__dict__.setdefault("verbose", False)
+        self.__dict__.setdefault("residualArgs", {"yh": None, "zh": None, "tendon_forces": None})
+
+    def to(self, device):
+        """Moves every tensor attribute and the MLP to `device` (a checkpoint written on another machine)."""
+        self.device = device
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        self.nn_models = self.nn_models.to(device)
+        if isinstance(self.residualArgs, dict):
+            self.residualArgs = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.residualArgs.items()}
+        self._handle = None
+        return self
+
     # ------------------------------------------------------------------
     # MLP
     # ------------------------------------------------------------------

@@ -417,6 +417,30 @@ def gen_train_step():
     save("train_step", **out)
 
 
+def gen_checkpoint():
+    """Checkpoint interchange: a file written exactly as physics_train.py:284-288 writes it
+    (torch.save({'robot': robot, 'dtw': ..., 'loss': ..., 'optim': ...})) with the REFERENCE classes,
+    plus what the reference computes with that robot.  The .pth holds pickled attribute values only."""
+    torch.manual_seed(3)
+    rob = ref_torch.CosseratRodTorch("cpu", 32)
+    ref_knode.setup_robot(rob, "damping")
+    opt = torch.optim.Adam(rob.nn_models.parameters(), lr=1e-2)
+    path = os.path.join(HERE, "ref_checkpoint.pth")
+    torch.save({"robot": rob, "dtw": [[1.5]], "loss": [0.25], "optim": opt.state_dict()}, path)
+    Q = 16
+    y, yh, zh, tens = sample_rows(Q, 4)
+    ty, tyh, tzh = (torch.tensor(a).float() for a in (y, yh, zh))
+    tf = torch.tensor(tens).float() @ rob.tendon_dirs
+    with torch.no_grad():
+        dys, z = rob.ODE_parallel(ty, tyh, tzh, tf)
+    # the NumPy class reading the same file (cosserat_ode.py:81-88 uses map_location 'mps'; cpu here)
+    nn_model = torch.load(path, map_location="cpu", weights_only=False)["robot"].nn_models
+    params = {k: v.detach().numpy() for k, v in nn_model.state_dict().items()}
+    save("checkpoint", y=y, yh=yh, zh=zh, tens=tens, par=torch.cat([dys, z], 1).numpy(),
+         L=np.float64(rob.L), del_t=np.float64(rob.del_t), E=np.float64(rob.E), Bbt=rob.Bbt.numpy(),
+         layer_strings=np.array([str(l) for l in nn_model]), **{"p_" + k: v for k, v in params.items()})
+
+
 def gen_small():
     """F8: calc_controls and quaternion_to_euler."""
     out = {}
@@ -438,6 +462,7 @@ ALL = {
     "ode_kat": gen_ode_kat, "ode_torch_kat": gen_ode_torch_kat, "residual_kat": gen_residual_kat,
     "sim_cfg1": gen_sim_cfg1, "sim_n100": gen_sim_n100, "sim_n400": gen_sim_n400, "sim_misc": gen_sim_misc,
     "sim_nn": gen_sim_nn, "train_step": gen_train_step, "small": gen_small,
+    "checkpoint": gen_checkpoint,
 }
 
 if __name__ == "__main__":

@@ -297,3 +297,28 @@ def test_ode_parallel_and_pickle(torch_cuda):
     rob2 = torch.load(buf, weights_only=False)["robot"]
     dys2, z2 = rob2.ODE_parallel(t(gk["y"]), t(gk["yh"]), t(gk["zh"]), tf)
     assert torch.equal(dys2, dys) and torch.equal(z2, z)
+
+
+def test_reference_checkpoint_runs_on_gpu(torch_cuda):
+    """A checkpoint written by the reference classes (tests/golden/ref_checkpoint.pth) loaded through
+    krod_checkpoint and evaluated by the HIP kernels reproduces the reference's ODE_parallel output; the same
+    file feeds the NumPy-side class exactly as cosserat_ode.py:81-88 / physics_train.py:104-110 do."""
+    torch = torch_cuda
+    import os
+    import krod_checkpoint as kc
+    from conftest import GOLDEN
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot
+    g = load_golden("checkpoint")
+    path = os.path.join(GOLDEN, "ref_checkpoint.pth")
+    rob = kc.load_checkpoint(path, DEV)["robot"]
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    tf = t(g["tens"]) @ rob.tendon_dirs
+    dys, z = rob.ODE_parallel(t(g["y"]), t(g["yh"]), t(g["zh"]), tf)
+    assert rel_l2(torch.cat([dys, z], 1).detach().cpu().numpy(), g["par"]) < 2e-6
+    # NumPy-side robot reading the same file (fp64 evaluation of the fp32-trained weights)
+    r = CosseratRod(nn_path=path, use_fsolve=True)
+    setup_robot(r, "damping")
+    assert len(r.param_ls) == 4 and r.param_ls[0].shape == (32, 28)
+    ys, zz = r.ODE(g["y"][0], g["yh"][0], g["zh"][0], (g["tens"][0] @ r.tendon_dirs))
+    assert rel_l2(np.concatenate([ys, zz]), g["par"][0]) < 5e-6

@@ -15,6 +15,8 @@ import pytest
 
 from conftest import ROOT, load_golden
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
 import cosserat_oracle as orc
 
 HEADER = os.path.join(ROOT, "include", "knode_rod.h")
@@ -231,3 +233,37 @@ def test_data_parallel_allreduce_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"ok {r}" in o
+
+
+def test_reference_checkpoint_loads_without_reference_code(tmp_path):
+    """tests/golden/ref_checkpoint.pth was written by the REFERENCE classes exactly as physics_train.py:
+    284-288 does.  With this package on sys.path it unpickles into our CosseratRodTorch (no reference code
+    anywhere), with the same attributes and weights; the weights-only format round-trips."""
+    import torch
+    import krod_checkpoint as kc
+    from cosserat_ode_torch import CosseratRodTorch
+    g = load_golden("checkpoint")
+    ckpt = kc.load_checkpoint(os.path.join(GOLDEN, "ref_checkpoint.pth"), "cpu")
+    rob = ckpt["robot"]
+    assert type(rob) is CosseratRodTorch and type(rob).__module__ == "cosserat_ode_torch"
+    assert "/root/reference" not in (sys.modules["cosserat_ode_torch"].__file__ or "")
+    assert ckpt["dtw"] == [[1.5]] and ckpt["loss"] == [0.25] and "state" in ckpt["optim"]
+    assert rob.L == float(g["L"]) and rob.del_t == float(g["del_t"]) and rob.E == float(g["E"])
+    assert np.array_equal(rob.Bbt.numpy(), g["Bbt"])
+    assert [str(l) for l in rob.nn_models] == [str(s) for s in g["layer_strings"]]
+    sd = rob.nn_models.state_dict()
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), g["p_" + k])
+    # the NumPy class's reader (cosserat_ode.py:81-88)
+    nn_model = torch.load(os.path.join(GOLDEN, "ref_checkpoint.pth"), map_location="cpu", weights_only=False)["robot"].nn_models
+    assert len(nn_model) == 3
+    # weights-only round trip
+    kc.save_weights(tmp_path / "w.npz", rob.nn_models)
+    ml, param_ls = kc.load_weights(tmp_path / "w.npz")
+    assert [str(l) for l in ml] == [str(l) for l in rob.nn_models]
+    for a, (k, v) in zip(param_ls, sd.items()):
+        assert np.array_equal(a, v.numpy())
+    # and our own checkpoint goes through the same door
+    kc.save_checkpoint(tmp_path / "ours.pth", rob, dtw=[[2.0]], loss=[0.5])
+    again = kc.load_checkpoint(tmp_path / "ours.pth")["robot"]
+    assert torch.equal(again.nn_models[0].weight, rob.nn_models[0].weight)
