@@ -110,6 +110,10 @@ int kr_default_params(kr_params* out);
 /* applies knode.setup_robot (knode.py:6-53); mod NULL or "" = no modifier.
  * Unknown mod -> KR_E_ARG, like the reference's exception. */
 int kr_apply_preset(kr_params* inout, const char* mod);
+/* The legacy ("original") parameter set of knode_cosserat_realworld/prepare.py:35-73
+ * (setup_robot_original: del_t 0.005, L 0.4, E 209e9, r 0.0012, rho 8000, Bbt 5e-4 I) with its own
+ * modifiers None|nsw|short|damping|diameter|youngs|dampstiff|lengthstiff. */
+int kr_apply_preset_original(kr_params* inout, const char* mod);
 
 int kr_create(const kr_params* p, int device, kr_handle** out);
 int kr_destroy(kr_handle* h);

@@ -250,6 +250,35 @@ int kr_apply_preset(kr_params* p, const char* mod) {
   return KR_OK;
 }
 
+int kr_apply_preset_original(kr_params* p, const char* mod) {
+  KR_CHECK_PTR(p);
+  p->del_t = 0.005; p->L = 0.4; p->E = 209e9; p->r = 0.0012; p->rho = 8000.0;
+  double bbt = 5e-4;
+  const std::string m = mod ? mod : "";
+  if (m.empty() || m == "None") {
+  } else if (m == "nsw") {
+    p->g[0] = p->g[1] = p->g[2] = 0;
+  } else if (m == "short") {
+    p->L = 0.3;
+  } else if (m == "damping") {
+    bbt = 9e-4;
+  } else if (m == "diameter") {
+    p->r = 0.002;
+  } else if (m == "youngs") {
+    p->E = 109e9;
+  } else if (m == "dampstiff") {
+    bbt = 3e-2; p->E = 109e9;
+  } else if (m == "lengthstiff") {
+    p->L = 0.3; p->E = 109e9;
+  } else {
+    set_error("Unknown mod " + m);
+    return KR_E_ARG;
+  }
+  for (int i = 0; i < 9; ++i) p->Bbt[i] = 0;
+  p->Bbt[0] = p->Bbt[4] = p->Bbt[8] = bbt;
+  return KR_OK;
+}
+
 int kr_set_params(kr_handle* h, const kr_params* p) {
   KR_CHECK_H(h);
   KR_CHECK_PTR(p);

@@ -57,6 +57,30 @@ def setup_robot(robot, mod=None, original=False):
     robot.compute_intermediate_terms()
 
 
+def setup_robot_original(robot, mod=None):
+    """The legacy parameter set, knode_cosserat_realworld/prepare.py:35-73 (``setup_robot(robot, mod,
+    original=True)`` there): del_t 0.005, L 0.4, E 209e9, r 0.0012, rho 8000, Bbt 5e-4, modifiers
+    None / nsw / short / damping / diameter / youngs / dampstiff / lengthstiff."""
+    p = kn.KrParams()
+    kn.check(kn.load().kr_default_params(p))
+    for k in range(3):
+        p.g[k] = float(np.asarray(_to_numpy(robot.g)).reshape(-1)[k])
+    rc = kn.load().kr_apply_preset_original(p, None if mod is None else str(mod).encode())
+    if rc != 0:
+        raise Exception("Unknown mod " + str(mod))
+    robot.del_t, robot.L, robot.E, robot.r, robot.rho = p.del_t, p.L, p.E, p.r, p.rho
+    is_np = isinstance(robot, CosseratRod)
+    if mod == "nsw":
+        robot.g = _like(robot, [0, 0, 0], is_np)
+    bbt = p.Bbt[0]
+    if is_np:
+        robot.Bbt = np.diag([bbt, bbt, bbt])
+    else:
+        import torch
+        robot.Bbt = torch.diag(torch.tensor([bbt, bbt, bbt], device=robot.device))
+    robot.compute_intermediate_terms()
+
+
 def _to_numpy(a):
     if hasattr(a, "detach"):
         return a.detach().cpu().numpy()

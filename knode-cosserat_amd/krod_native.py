@@ -58,6 +58,7 @@ _PROTOS = {
     "kr_version": (_int, []),
     "kr_default_params": (_int, [C.POINTER(KrParams)]),
     "kr_apply_preset": (_int, [C.POINTER(KrParams), C.c_char_p]),
+    "kr_apply_preset_original": (_int, [C.POINTER(KrParams), C.c_char_p]),
     "kr_create": (_int, [C.POINTER(KrParams), _int, C.POINTER(_vp)]),
     "kr_destroy": (_int, [_vp]),
     "kr_set_option": (_int, [_vp, C.c_char_p, _int]),

@@ -403,3 +403,22 @@ def test_error_paths(torch_cuda):
         h.step(st[0].cpu(), st[1], st[2], G, tens)
     # empty batch is a no-op
     h.step(st[0][:0], st[1][:0], st[2][:0], G[:0], tens[:0])
+
+
+def test_simulate_legacy_preset(torch_cuda):
+    """prepare.py:35-73 parameters (del_t 0.005, steel rod): forward simulation against the oracle."""
+    import cosserat_oracle as orc
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot_original, simulate
+    r = CosseratRod(use_fsolve=True)
+    setup_robot_original(r, "damping")
+    r.N = 20
+    r.compute_intermediate_terms()
+    P = orc.RodParams()
+    P.N, P.del_t, P.L, P.E, P.r, P.rho = 20, 0.005, 0.4, 209e9, 0.0012, 8000.0
+    P.Bbt = np.diag([9e-4] * 3)
+    T = 40
+    ctl = np.array(orc.calc_controls("sine", 0.5, P.del_t, T))
+    want = orc.simulate(P.derived(), ctl, solver="fsolve")
+    got = simulate(r, ctl)
+    assert rel_l2(got[:, :25], want[:, :25]) < 1e-8

@@ -322,3 +322,38 @@ def test_reference_checkpoint_runs_on_gpu(torch_cuda):
     assert len(r.param_ls) == 4 and r.param_ls[0].shape == (32, 28)
     ys, zz = r.ODE(g["y"][0], g["yh"][0], g["zh"][0], (g["tens"][0] @ r.tendon_dirs))
     assert rel_l2(np.concatenate([ys, zz]), g["par"][0]) < 5e-6
+
+
+def test_evaluate_closed_loop_rollout(torch_cuda):
+    """physics_train.py:136-167: live weights of the torch robot are injected into the NumPy-side robot and
+    rolled out in closed loop; the rollout is the golden NN-on simulate (sim_nn fixture), the score a DTW."""
+    torch = torch_cuda
+    import torch.nn as nn
+    import krod_eval as ke
+    from cosserat_ode import CosseratRod
+    from cosserat_ode_torch import CosseratRodTorch
+    from knode import setup_robot, simulate
+    g = load_golden("sim_nn")
+    rob = CosseratRodTorch(DEV, 64)
+    with torch.no_grad():  # the weights the reference ran the fixture with (fp64 there; fp32 parameters here)
+        rob.nn_models[0].weight.copy_(torch.tensor(g["mlp_elu64_W0"]))
+        rob.nn_models[0].bias.copy_(torch.tensor(g["mlp_elu64_b0"]))
+        rob.nn_models[2].weight.copy_(torch.tensor(g["mlp_elu64_W1"]))
+        rob.nn_models[2].bias.copy_(torch.tensor(g["mlp_elu64_b1"]))
+    r_eval = CosseratRod(use_fsolve=True)
+    setup_robot(r_eval)
+    r_eval.N = int(g["elu64_N"])
+    r_eval.compute_intermediate_terms()
+    ctl = g["elu64_ctl"]
+    r_plain = CosseratRod(use_fsolve=True)
+    setup_robot(r_plain)
+    r_plain.N = r_eval.N
+    r_plain.compute_intermediate_terms()
+    ref = simulate(r_plain, ctl)[:, :25]
+    dtw, traj = ke.evaluate(r_eval, rob, ctl, ref)
+    assert np.isfinite(dtw) and dtw > 0  # the MLP changes the tip path
+    assert r_eval.nn_path == "whatever" and len(r_eval.param_ls) == 4
+    again = simulate(r_eval, ctl)[: len(traj), :25]
+    assert np.array_equal(again, traj)
+    # the reference's own NN-on rollout (weights there in fp64: agreement at the fp32 rounding of the parameters)
+    assert rel_l2(traj, g["elu64_traj"][: len(traj), :25]) < 1e-5

@@ -267,3 +267,59 @@ def test_reference_checkpoint_loads_without_reference_code(tmp_path):
     kc.save_checkpoint(tmp_path / "ours.pth", rob, dtw=[[2.0]], loss=[0.5])
     again = kc.load_checkpoint(tmp_path / "ours.pth")["robot"]
     assert torch.equal(again.nn_models[0].weight, rob.nn_models[0].weight)
+
+
+def test_dtw_and_eval_metrics(tmp_path):
+    """krod_eval: exact DTW against the textbook recursion, the pos+Euler MSE against a direct evaluation,
+    and the reference's trajectory file layout."""
+    import krod_eval as ke
+    rng = np.random.default_rng(0)
+    for (ta, tb, d) in ((1, 1, 3), (5, 9, 3), (40, 33, 3), (17, 17, 1)):
+        a, b = rng.standard_normal((ta, d)), rng.standard_normal((tb, d))
+        D = np.full((ta + 1, tb + 1), np.inf)
+        D[0, 0] = 0
+        for i in range(1, ta + 1):
+            for j in range(1, tb + 1):
+                D[i, j] = np.abs(a[i - 1] - b[j - 1]).sum() + min(D[i - 1, j], D[i, j - 1], D[i - 1, j - 1])
+        assert abs(ke.dtw_distance(a, b) - D[ta, tb]) < 1e-12 * max(1.0, D[ta, tb])
+    x = rng.standard_normal(30)
+    assert ke.dtw_distance(x, x) == 0.0
+    assert ke.dtw_distance(np.repeat(x, 2), x) == 0.0  # warping absorbs a uniform slow-down
+    # pos + euler MSE
+    T, N = 6, 5
+    tr = rng.standard_normal((T, 25, N)); rf = tr + 0.01 * rng.standard_normal((T, 25, N))
+    tr[:, 3] += 3; rf[:, 3] += 3
+    m = ke.pos_euler_mse(tr, rf)
+    eul = lambda q: np.array([orc.quaternion_to_euler(qq / np.linalg.norm(qq)) for qq in q])
+    q1 = tr[:, 3:7].transpose(0, 2, 1).reshape(-1, 4); q2 = rf[:, 3:7].transpose(0, 2, 1).reshape(-1, 4)
+    assert m > 0 and np.isfinite(m)
+    se_pos = ((tr[:, :3] - rf[:, :3]).reshape(-1, 3)) ** 2
+    from scipy.spatial.transform import Rotation
+    e1 = Rotation.from_quat(q1[:, [1, 2, 3, 0]]).as_euler("zyx"); e2 = Rotation.from_quat(q2[:, [1, 2, 3, 0]]).as_euler("zyx")
+    assert abs(m - np.mean(np.concatenate([(e1 - e2) ** 2, se_pos])) * 1000) < 1e-12
+    # file layout of simulate.py:97-100
+    ke.save_trajectory(tmp_path / "t.npy", np.zeros((4, 50, 3)), np.ones((3, 4)))
+    d = np.load(tmp_path / "t.npy", allow_pickle=True).item()
+    assert d["traj"].shape == (4, 50, 3) and d["controls"].shape == (3, 4)
+    t2, c2 = ke.load_trajectory(tmp_path / "t.npy")
+    assert t2.dtype == np.float64 and np.array_equal(c2, np.ones((3, 4)))
+
+
+def test_legacy_preset_table():
+    """kr_apply_preset_original restates knode_cosserat_realworld/prepare.py:35-73 (host only)."""
+    import krod_native as kn
+    lib = kn.load()
+    want = {  # mod: (L, E, r, Bbt, g_z)
+        None: (0.4, 209e9, 0.0012, 5e-4, -9.81), "nsw": (0.4, 209e9, 0.0012, 5e-4, 0.0),
+        "short": (0.3, 209e9, 0.0012, 5e-4, -9.81), "damping": (0.4, 209e9, 0.0012, 9e-4, -9.81),
+        "diameter": (0.4, 209e9, 0.002, 5e-4, -9.81), "youngs": (0.4, 109e9, 0.0012, 5e-4, -9.81),
+        "dampstiff": (0.4, 109e9, 0.0012, 3e-2, -9.81), "lengthstiff": (0.3, 109e9, 0.0012, 5e-4, -9.81),
+    }
+    for mod, (L, E, r, bbt, gz) in want.items():
+        p = kn.KrParams()
+        kn.check(lib.kr_default_params(p))
+        assert lib.kr_apply_preset_original(p, None if mod is None else mod.encode()) == 0
+        assert (p.del_t, p.L, p.E, p.r, p.rho) == (0.005, L, E, r, 8000.0)
+        assert [p.Bbt[i] for i in range(9)] == [bbt, 0, 0, 0, bbt, 0, 0, 0, bbt] and p.g[2] == gz
+    p = kn.KrParams()
+    assert lib.kr_apply_preset_original(p, b"noair") != 0  # not a modifier of the legacy set
