@@ -441,6 +441,38 @@ def gen_checkpoint():
          layer_strings=np.array([str(l) for l in nn_model]), **{"p_" + k: v for k, v in params.items()})
 
 
+def gen_estimate_state():
+    """knode_cosserat_realworld/estimate_state.py run on poses taken from a simulated
+    trajectory (N = 10 grid points, the only size its hard-coded index 9 is meant for) and on an N = 12
+    variant that exercises the wrap-around of that quirk."""
+    rw = "/root/reference/knode_cosserat_realworld"
+    import importlib.util
+    argv, sys.argv = sys.argv, ["x"]
+    sys.path.insert(0, rw)
+    try:
+        spec = importlib.util.spec_from_file_location("ref_estimate_state", os.path.join(rw, "estimate_state.py"))
+        es = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(es)
+    finally:
+        sys.path.remove(rw)
+        sys.argv = argv
+    out = {}
+    for N in (10, 12):
+        r = np_robot(None, N)
+        T = 40
+        ctl = np.array(ref_ctl.calc_controls("sine", 1.0, r.del_t, T))
+        traj = ref_knode.simulate(r, ctl)[:, :25]
+        rng = np.random.default_rng(N)
+        data = traj[:, :7, :] + 1e-4 * rng.standard_normal(traj[:, :7, :].shape)  # measurement noise
+        r2 = np_robot(None, N)
+        est = es.estimate_state(data.copy(), ctl.copy(), r2)
+        out[f"N{N}_data"] = data
+        out[f"N{N}_ctl"] = ctl
+        out[f"N{N}_est"] = est
+        out[f"N{N}_vstar_after"] = np.array(r2.vstar, dtype=np.float64)
+    save("estimate_state", **out)
+
+
 def gen_small():
     """F8: calc_controls and quaternion_to_euler."""
     out = {}
@@ -462,7 +494,7 @@ ALL = {
     "ode_kat": gen_ode_kat, "ode_torch_kat": gen_ode_torch_kat, "residual_kat": gen_residual_kat,
     "sim_cfg1": gen_sim_cfg1, "sim_n100": gen_sim_n100, "sim_n400": gen_sim_n400, "sim_misc": gen_sim_misc,
     "sim_nn": gen_sim_nn, "train_step": gen_train_step, "small": gen_small,
-    "checkpoint": gen_checkpoint,
+    "checkpoint": gen_checkpoint, "estimate_state": gen_estimate_state,
 }
 
 if __name__ == "__main__":

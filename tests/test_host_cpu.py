@@ -323,3 +323,24 @@ def test_legacy_preset_table():
         assert [p.Bbt[i] for i in range(9)] == [bbt, 0, 0, 0, bbt, 0, 0, 0, bbt] and p.g[2] == gz
     p = kn.KrParams()
     assert lib.kr_apply_preset_original(p, b"noair") != 0  # not a modifier of the legacy set
+
+
+@pytest.mark.parametrize("N", [10, 12])
+def test_estimate_state_matches_reference(N):
+    """krod_estimate.estimate_state against knode_cosserat_realworld/estimate_state.py:158-242 run by the
+    reference (fixture estimate_state.npz); host-side, needs only kr_derive from the library."""
+    import krod_estimate as kest
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot
+    g = load_golden("estimate_state")
+    r = CosseratRod(use_fsolve=True)
+    setup_robot(r)
+    r.N = N
+    r.compute_intermediate_terms()
+    est = kest.estimate_state(g[f"N{N}_data"], g[f"N{N}_ctl"], r)
+    want = g[f"N{N}_est"]
+    assert est.shape == want.shape
+    for rows, name in ((slice(0, 7), "p,h"), (slice(13, 19), "q,w"), (slice(7, 13), "n,m"), (slice(19, 25), "v,u")):
+        err = np.linalg.norm(est[:, rows] - want[:, rows]) / np.linalg.norm(want[:, rows])
+        assert err < 1e-9, (name, err)
+    assert np.array_equal(np.asarray(r.vstar, dtype=np.float64), g[f"N{N}_vstar_after"])
