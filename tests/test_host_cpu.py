@@ -343,4 +343,4 @@ def test_estimate_state_matches_reference(N):
     for rows, name in ((slice(0, 7), "p,h"), (slice(13, 19), "q,w"), (slice(7, 13), "n,m"), (slice(19, 25), "v,u")):
         err = np.linalg.norm(est[:, rows] - want[:, rows]) / np.linalg.norm(want[:, rows])
         assert err < 1e-9, (name, err)
-    assert np.array_equal(np.asarray(r.vstar, dtype=np.float64), g[f"N{N}_vstar_after"])
+    assert np.allclose(np.asarray(r.vstar, dtype=np.float64), g[f"N{N}_vstar_after"], rtol=0, atol=1e-12)
