@@ -8,6 +8,9 @@
 // tile of 128 rows through LDS: global -> LDS with fully coalesced contiguous
 // reads, compute from LDS with a conflict-free odd row pitch, results back to
 // LDS and out with contiguous writes.
+#include <cstdint>
+#include <type_traits>
+
 #include "kr_internal.hpp"
 #include "mlp_lane.hpp"
 
@@ -27,24 +30,72 @@ __device__ __forceinline__ void tile_out(T* __restrict__ g, const T* l, int64_t 
   const int64_t lim = (Q - row0 < ODE_ROWS ? Q - row0 : ODE_ROWS) * width;
   for (int64_t i = tid; i < lim; i += ODE_ROWS) g[base + i] = l[i];
 }
+// Full tiles of 16-byte aligned arrays: 16 bytes per lane, every load of the tile issued before the first
+// LDS write (the scalar forms above keep one 4/8-byte access in flight per lane and reach a quarter of the
+// HBM rate).  WIDTH * ODE_ROWS * sizeof(T) is a multiple of 16 for every row width used here.
+template <typename T, int WIDTH>
+struct TileVec {
+  using V = typename std::conditional<sizeof(T) == 8, double __attribute__((ext_vector_type(2))),
+                                      float __attribute__((ext_vector_type(4)))>::type;
+  static constexpr int PER = 16 / sizeof(T);
+  static constexpr int NVEC = ODE_ROWS * WIDTH / PER;
+  static constexpr int TRIPS = (NVEC + ODE_ROWS - 1) / ODE_ROWS;
+  static_assert((ODE_ROWS * WIDTH) % PER == 0, "tile is not a whole number of 16-byte vectors");
+  V r[TRIPS];
+  __device__ __forceinline__ void load(const T* __restrict__ g, int64_t row0, int tid) {
+    const V* src = reinterpret_cast<const V*>(g + row0 * WIDTH);
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int i = tid + k * ODE_ROWS;
+      if (i < NVEC) r[k] = __builtin_nontemporal_load(src + i);
+    }
+  }
+  __device__ __forceinline__ void to_lds(T* l, int tid) const {
+    V* dst = reinterpret_cast<V*>(l);
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int i = tid + k * ODE_ROWS;
+      if (i < NVEC) dst[i] = r[k];
+    }
+  }
+  static __device__ __forceinline__ void store(T* __restrict__ g, const T* l, int64_t row0, int tid) {
+    V* dst = reinterpret_cast<V*>(g + row0 * WIDTH);
+    const V* src = reinterpret_cast<const V*>(l);
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int i = tid + k * ODE_ROWS;
+      if (i < NVEC) __builtin_nontemporal_store(src[i], dst + i);
+    }
+  }
+};
 
 template <typename T, bool DIAG, bool NN, bool NNHIST>
 __global__ __launch_bounds__(ODE_ROWS) void ode_batch_kernel(const RodConst<T> P, const MlpDev<T> M, int64_t Q,
                                                              const T* __restrict__ y, const T* __restrict__ yh,
                                                              const T* __restrict__ zh, const T* __restrict__ tf,
-                                                             T* __restrict__ dys, T* __restrict__ z, T* act_ws) {
+                                                             T* __restrict__ dys, T* __restrict__ z, T* act_ws,
+                                                             int vec_ok) {
   // LDS: y[128][19] yh[128][19] zh[128][6] tf[128][3]  (47 per row; odd pitches 19/19 and 6,3 are read
   // row-per-lane: bank = (row*pitch + c) mod 32/64 - pitch 19 is conflict free, 6 and 3 are 2-way at worst)
-  __shared__ T sy[ODE_ROWS * 19];
-  __shared__ T syh[ODE_ROWS * 19];
-  __shared__ T szh[ODE_ROWS * 6];
-  __shared__ T stf[ODE_ROWS * 3];
+  __shared__ __attribute__((aligned(16))) T sy[ODE_ROWS * 19];
+  __shared__ __attribute__((aligned(16))) T syh[ODE_ROWS * 19];
+  __shared__ __attribute__((aligned(16))) T szh[ODE_ROWS * 6];
+  __shared__ __attribute__((aligned(16))) T stf[ODE_ROWS * 3];
   const int tid = threadIdx.x;
   for (int64_t row0 = (int64_t)blockIdx.x * ODE_ROWS; row0 < Q; row0 += (int64_t)gridDim.x * ODE_ROWS) {
-    tile_in(y, sy, row0, Q, 19, tid);
-    tile_in(yh, syh, row0, Q, 19, tid);
-    tile_in(zh, szh, row0, Q, 6, tid);
-    tile_in(tf, stf, row0, Q, 3, tid);
+    const bool full = vec_ok && row0 + ODE_ROWS <= Q;  // uniform per workgroup
+    if (full) {
+      TileVec<T, 19> a, b;
+      TileVec<T, 6> c;
+      TileVec<T, 3> d;
+      a.load(y, row0, tid); b.load(yh, row0, tid); c.load(zh, row0, tid); d.load(tf, row0, tid);
+      a.to_lds(sy, tid); b.to_lds(syh, tid); c.to_lds(szh, tid); d.to_lds(stf, tid);
+    } else {
+      tile_in(y, sy, row0, Q, 19, tid);
+      tile_in(yh, syh, row0, Q, 19, tid);
+      tile_in(zh, szh, row0, Q, 6, tid);
+      tile_in(tf, stf, row0, Q, 3, tid);
+    }
     __syncthreads();
     T yr[19];
 #pragma unroll
@@ -106,8 +157,13 @@ __global__ __launch_bounds__(ODE_ROWS) void ode_batch_kernel(const RodConst<T> P
 #pragma unroll
     for (int c = 0; c < 6; ++c) szh[tid * 6 + c] = out[19 + c];
     __syncthreads();
-    tile_out(dys, sy, row0, Q, 19, tid);
-    tile_out(z, szh, row0, Q, 6, tid);
+    if (full) {
+      TileVec<T, 19>::store(dys, sy, row0, tid);
+      TileVec<T, 6>::store(z, szh, row0, tid);
+    } else {
+      tile_out(dys, sy, row0, Q, 19, tid);
+      tile_out(z, szh, row0, Q, 6, tid);
+    }
     __syncthreads();
   }
 }
@@ -175,11 +231,13 @@ int launch_ode_batch(kr_handle* h, int64_t Q, const T* y, const T* yh, const T* 
   do {                                                                                                      \
     if (P.diag)                                                                                             \
       hipLaunchKernelGGL((ode_batch_kernel<T, true, NNv, Hv>), dim3(grid), dim3(ODE_ROWS), 0, s, P, M, Q, y, yh, zh, \
-                         tf, dys, z, act);                                                                  \
+                         tf, dys, z, act, vec_ok);                                                          \
     else                                                                                                    \
       hipLaunchKernelGGL((ode_batch_kernel<T, false, NNv, Hv>), dim3(grid), dim3(ODE_ROWS), 0, s, P, M, Q, y, yh, zh, \
-                         tf, dys, z, act);                                                                  \
+                         tf, dys, z, act, vec_ok);                                                          \
   } while (0)
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec_ok = al(y) && al(yh) && al(zh) && al(tf) && al(dys) && al(z);
   if (!use_nn) KR_LAUNCH(false, false);
   else if (!hist) KR_LAUNCH(true, false);
   else KR_LAUNCH(true, true);
