@@ -123,11 +123,14 @@ int kr_destroy(kr_handle* h);
  *   "ms_batch_limit" auto mode uses it when B <= limit (default 2048)
  *   "persistent"     1 (default) / 0: kr_simulate_batch runs all steps in one launch when the
  *                    multiple-shooting kernel applies
- *   "predictor"      0..7: highest order of the time extrapolation kr_simulate_batch uses for
- *                    the initial guess of each step (default 7; 0 = the reference's warm start).
- *                    The persistent kernel picks, rod by rod and step by step, the order <= this
- *                    that would have predicted the step just solved best; one launch per step
- *                    uses min(this, 2) */
+ *   "predictor"      0..8: how kr_simulate_batch may form the initial guess of each step (default 8;
+ *                    0 = the reference's warm start).  1..7: highest order of polynomial time
+ *                    extrapolation; the persistent kernel picks, rod by rod and step by step, the
+ *                    order <= this that would have predicted the step just solved best.  8 adds a
+ *                    three-tap linear recurrence fitted per rod to the last steps, used whenever
+ *                    it predicted the step just solved better than every polynomial.  One launch
+ *                    per step uses min(this, 2).  The guess never changes the solution, only the
+ *                    number of Newton sweeps. */
 int kr_set_option(kr_handle* h, const char* name, int value);
 /* reads an option back; additionally "last_sim_path": what the last kr_simulate_batch did -
  * 0 one single-shooting launch per step, 1 one multiple-shooting launch per step, 2 one

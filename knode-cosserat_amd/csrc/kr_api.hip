@@ -338,7 +338,7 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
   } else if (n == "mfma_mlp") {
     h->mfma_mlp = value ? 1 : 0;  // takes effect at the next kr_set_mlp
   } else if (n == "predictor") {
-    if (value < 0 || value > 7) { set_error("predictor must be 0 .. 7"); return KR_E_ARG; }
+    if (value < 0 || value > 8) { set_error("predictor must be 0 .. 8"); return KR_E_ARG; }
     h->predictor = value;
   } else {
     set_error("unknown option " + n);

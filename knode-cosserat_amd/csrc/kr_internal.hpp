@@ -58,7 +58,7 @@ struct kr_handle {
   int lds_limit = 160 * 1024;
   int ms_mode = -1;          // multiple-shooting step kernel: -1 auto (by batch size), 0 off, 1 forced
   int ms_batch_limit = 2048; // auto mode: use it when B <= this
-  int predictor = 7;         // highest extrapolation order kr_simulate_batch may use (per-step launches: <= 2)
+  int predictor = 8;         // highest extrapolation order kr_simulate_batch may use (per-step launches: <= 2)
   int last_sim_path = 0;     // what the last kr_simulate_batch did: 0 one single-shooting launch per step,
                              // 1 one multiple-shooting launch per step, 2 one persistent launch for all steps
   void* dbg = nullptr;       // diagnostic cycle-counter buffer (kr_debug_buffer)

@@ -81,6 +81,22 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
   const float r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+// sum over the 64 lanes (all active) of a double: DPP within rows of 16, then 4 x 2 readlanes
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += quad_xor<0xB1>(v);
+  v += quad_xor<0x4E>(v);
+  v += quad_xor<0x141>(v);  // row_half_mirror
+  v += quad_xor<0x140>(v);  // row_mirror
+  const long long b = __double_as_longlong(v);
+  const int lo = (int)(b & 0xFFFFFFFFll), hi = (int)(b >> 32);
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int l = __builtin_amdgcn_readlane(lo, 16 * r), h = __builtin_amdgcn_readlane(hi, 16 * r);
+    s += __longlong_as_double(((long long)h << 32) | (unsigned int)l);
+  }
+  return s;
+}
 template <typename T>
 __device__ __forceinline__ void load_pair(const T* src, T& a, T& b) {
   typedef T V2 __attribute__((ext_vector_type(2)));
@@ -101,6 +117,7 @@ __device__ __forceinline__ T extrapolate(int order, T g0, T g1, T g2) {
   return T(3) * (g0 - g1) + g2;
 }
 
+constexpr int MS_ORDER_LP = 8;  // "order" code of the adaptive linear predictor (see ms_sim_kernel)
 constexpr int MS_HLEV = 8;  // time levels of the unknowns the persistent kernel keeps (predictor order <= 7)
 // polynomial extrapolation one step ahead from the newest `order + 1` levels h[0] (newest) .. h[order]:
 // sum_k (-1)^k C(order+1, k+1) h[k]
@@ -787,6 +804,12 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   S.kappa = T(0);
   int avail = A.prev_init ? 1 : 0;  // time levels behind states[0] that carry information
   int next_order = avail < A.predictor ? avail : A.predictor;  // extrapolation order of the coming step
+  if (next_order >= MS_HLEV) next_order = MS_HLEV - 1;
+  // adaptive linear predictor: x(t+1) ~ a0 x(t) + a1 (x(t) - x(t-1)) + a2 (x(t) - 2 x(t-1) + x(t-2)) with the
+  // three coefficients fitted per rod (a = (1, 1, 1) is quadratic extrapolation)
+  double lpa[3] = {1.0, 1.0, 1.0};
+  bool lp_have = false;  // lpa was fitted on the previous step (so it can be tested on this one)
+  bool lp_good = false;  // ... and predicted this step to better than 1e-3
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];
@@ -833,7 +856,13 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
         const int e = lane + q * WAVE;
         if (e < MS_NE) {
           const int i = e / 19, r = e - i * 19;
-          T g = extrapolate_n<T>(order, Hx[q]);
+          T g;
+          if (order == MS_ORDER_LP) {
+            const double h0 = (double)Hx[q][0], h1 = (double)Hx[q][1], h2 = (double)Hx[q][2];
+            g = (T)(lpa[0] * h0 + lpa[1] * (h0 - h1) + lpa[2] * (h0 - 2.0 * h1 + h2));
+          } else {
+            g = extrapolate_n<T>(order, Hx[q]);
+          }
           if (i == 0) {
             T bc;
             if (ms_base_bc(L.cold, r, bc)) g = bc;
@@ -862,22 +891,76 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     // until the jump has left the stencil; fresh random controls every step stay at order 0, which
     // is the reference's warm start, knode.py:89)
     {
+      // (while the fitted recurrence below is in use and predicts to better than 1e-3 the polynomial orders
+      // are not evaluated at all: their errors would only be compared with a much smaller one)
+      const bool poly_eval = !(order == MS_ORDER_LP && lp_good);
       float err[MS_HLEV];
 #pragma unroll
       for (int p = 0; p < MS_HLEV; ++p) err[p] = 0.f;
+      if (poly_eval) {
+#pragma unroll
+        for (int q = 0; q < MS_EPL; ++q) {
+          const int e = lane + q * WAVE;
+          if (e < MS_NE) {
+            const T x = L.Xs[e];
+#pragma unroll
+            for (int p = 0; p < MS_HLEV; ++p) err[p] = fmaxf(err[p], update_ratio(x - extrapolate_n<T>(p, Hx[q]), x));
+          }
+        }
+      }
+      // The unknowns of a rod driven by smooth inputs follow, over a few steps, a linear recurrence (a constant
+      // plus one dominant oscillation is reproduced exactly by three taps), which predicts far better than
+      // any fixed polynomial when the motion is fast against the time step: weighted least squares over the
+      // MS_P x 19 components for "this step from the previous three", tested on the step after.
+      float err_lp = 0.f;
+      double Sn[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
 #pragma unroll
       for (int q = 0; q < MS_EPL; ++q) {
         const int e = lane + q * WAVE;
         if (e < MS_NE) {
-          const T x = L.Xs[e];
-#pragma unroll
-          for (int p = 0; p < MS_HLEV; ++p) err[p] = fmaxf(err[p], update_ratio(x - extrapolate_n<T>(p, Hx[q]), x));
+          const double x = (double)L.Xs[e];
+          const double h0 = (double)Hx[q][0], h1 = (double)Hx[q][1], h2 = (double)Hx[q][2];
+          const double b0 = h0, b1 = h0 - h1, b2 = h0 - 2.0 * h1 + h2;
+          if (lp_have) err_lp = fmaxf(err_lp, update_ratio(x - (lpa[0] * b0 + lpa[1] * b1 + lpa[2] * b2), x));
+          const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
+          const double w0 = b0 * w, w1 = b1 * w, w2 = b2 * w, xw = x * w;
+          Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
+          Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
         }
       }
-      const int pmax = avail < A.predictor ? avail : A.predictor;  // orders the history supported
+      const float em_lp = wave_max_nonneg(err_lp);
+      const bool lp_tested = lp_have;
+      lp_have = false;
+      if (A.predictor >= MS_ORDER_LP && avail >= 2 && status == KR_ST_CONVERGED) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sn[k] = wave_sum_f64(Sn[k]);
+        // (N + lam diag N) a = r + lam diag(N) 1: ridge towards quadratic extrapolation, relative per column
+        const double lam = 1e-12;
+        double a6[3][4] = {{Sn[0] * (1 + lam), Sn[1], Sn[2], Sn[6] + lam * Sn[0]},
+                           {Sn[1], Sn[3] * (1 + lam), Sn[4], Sn[7] + lam * Sn[3]},
+                           {Sn[2], Sn[4], Sn[5] * (1 + lam), Sn[8] + lam * Sn[5]}};
+        // symmetric positive definite: elimination without pivoting
+        const double i0 = fast_rcp(a6[0][0]);
+        const double f1 = a6[1][0] * i0, f2 = a6[2][0] * i0;
+#pragma unroll
+        for (int c = 1; c < 4; ++c) { a6[1][c] -= f1 * a6[0][c]; a6[2][c] -= f2 * a6[0][c]; }
+        const double i1 = fast_rcp(a6[1][1]);
+        const double f3 = a6[2][1] * i1;
+        a6[2][2] -= f3 * a6[1][2]; a6[2][3] -= f3 * a6[1][3];
+        const double x2 = a6[2][3] * fast_rcp(a6[2][2]);
+        const double x1 = (a6[1][3] - a6[1][2] * x2) * i1;
+        const double x0 = (a6[0][3] - a6[0][1] * x1 - a6[0][2] * x2) * i0;
+        if (isfinite(x0) && isfinite(x1) && isfinite(x2) && fabs(x0) < 4.0 && fabs(x1) < 16.0 && fabs(x2) < 64.0) {
+          lpa[0] = x0; lpa[1] = x1; lpa[2] = x2;
+          lp_have = true;
+        }
+      }
+      const int pmax = avail < A.predictor ? avail : (A.predictor < MS_HLEV ? A.predictor : MS_HLEV - 1);  // orders the history supported
       float em[MS_HLEV];
 #pragma unroll
-      for (int p = 0; p < MS_HLEV; ++p) em[p] = wave_max_nonneg(err[p]);
+      for (int p = 0; p < MS_HLEV; ++p) em[p] = poly_eval ? wave_max_nonneg(err[p]) : 3.0e38f;
       // best order, at most two above the one just used (chance hits on rough data - where the errors
       // grow with the order - do not add up to a high order; on smooth data the errors of neighbouring
       // orders can tie, every second one gains)
@@ -887,7 +970,11 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
       for (int p = 1; p < MS_HLEV; ++p)
         if (p <= pmax && p <= order + 2 && em[p] < eb) { eb = em[p]; nxt = p; }
       if (nxt == avail && avail + 1 < MS_HLEV && avail + 1 <= A.predictor && nxt >= order) nxt = avail + 1;  // history still growing
+      if (!poly_eval) nxt = pmax;  // not measured this step: what smooth data would have picked
       next_order = nxt;
+      // the fitted recurrence takes over when its previous fit predicted this step better than every polynomial
+      lp_good = lp_tested && lp_have && em_lp < 1.0e-3f;
+      if (lp_tested && lp_have && (em_lp < eb || lp_good)) next_order = MS_ORDER_LP;
 #ifdef KR_MS_STAMPS
       stamps.osum += (unsigned long long)order; stamps.olast = order;
       for (int p = 0; p < MS_HLEV; ++p) stamps.em[p] = em[p];

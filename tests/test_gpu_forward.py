@@ -367,7 +367,7 @@ def test_adaptive_predictor_on_rough_inputs(torch_cuda, kind):
     dev = "cuda:0"
     ctl_t = torch.as_tensor(ctl, device=dev).contiguous()
     outs = []
-    for pred, persistent in ((7, 1), (0, 0)):
+    for pred, persistent in ((8, 1), (7, 1), (0, 0)):
         h.set_option("predictor", pred)
         h.set_option("persistent", persistent)
         st = h.new_state(B, torch.float64, n_slots=T + 1)
@@ -378,8 +378,9 @@ def test_adaptive_predictor_on_rough_inputs(torch_cuda, kind):
         torch.cuda.synchronize()
         assert int((status != 0).sum()) == 0
         outs.append(st[..., :25].cpu().numpy())
-    for t in (1, 29, 31, 35, 61, T):  # both solves stop at |update| <= 1e-8: agreement at that level
-        assert rel_l2(outs[0][t], outs[1][t]) < 1e-7
+    for t in (1, 29, 31, 35, 61, T):  # all solves stop at |update| <= 1e-8: agreement at that level
+        assert rel_l2(outs[0][t], outs[2][t]) < 1e-7
+        assert rel_l2(outs[1][t], outs[2][t]) < 1e-7
 
 
 def test_error_paths(torch_cuda):

@@ -15,7 +15,7 @@ ctl = 5.0 + 5.0 * rng.uniform(size=(B, T, 4))
 dev = "cuda:0"
 ctl_t = torch.as_tensor(ctl, device=dev).contiguous()
 ref = None
-for ms, pers, pred in ((0, 0, 0), (0, 0, 2), (1, 0, 0), (1, 0, 2), (1, 1, 0), (1, 1, 2), (1, 1, 7)):
+for ms, pers, pred in ((0, 0, 0), (0, 0, 2), (1, 0, 0), (1, 0, 2), (1, 1, 0), (1, 1, 2), (1, 1, 7), (1, 1, 8)):
     h.set_option("ms_mode", ms); h.set_option("persistent", pers); h.set_option("predictor", pred)
     st = h.new_state(B, torch.float64, n_slots=T + 1); h.init_straight(st[0])
     G = torch.zeros((B, 6), dtype=torch.float64, device=dev)

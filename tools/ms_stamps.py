@@ -15,7 +15,7 @@ h = r._native(); h.set_option("ms_mode", 1); h.set_option("persistent", 1)
 dbg = torch.zeros((B, 24), dtype=torch.int64, device=dev)
 kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
 ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 1235), device=dev).contiguous()
-for pred in (7,):
+for pred in (7, 8):
     h.set_option("predictor", pred)
     st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
     h.simulate(ctl[:, :21].contiguous(), st, G, ring=True)
