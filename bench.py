@@ -229,7 +229,7 @@ def main():
                 "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "fp64 VALU issue bound, not HBM bound: one rod per wavefront on each of the 1024 SIMDs, "
-                        "2-3 Newton sweeps x 25 grid points x ~180 fp64 instructions per step; VALU busy ~60% of wave cycles "
+                        "2 Newton sweeps x 25 grid points x ~180 fp64 instructions per step; VALU busy ~58% of wave cycles "
                         "(profiles/*pmc_sq.json, DESIGN.md section 4)",
             },
         }
