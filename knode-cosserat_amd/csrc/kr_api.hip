@@ -175,6 +175,20 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
     }
   }
   h->last_sim_path = 0;
+  // one launch per step: the multiple-shooting kernel carries its start-value predictor from launch to launch
+  // through an image in HBM (12 KB per rod; skipped for batches that would need more than 1 GB of it)
+  double* pred = nullptr;
+  if (h->predictor > 2 && h->ms_mode != 0 && (h->ms_mode == 1 || B <= (int64_t)h->ms_batch_limit)) {
+    const size_t need = (size_t)B * KR_PRED_IMG_DOUBLES * sizeof(double);
+    if (need <= ((size_t)1 << 30)) {
+      if (need > h->pred_bytes) {
+        if (h->pred_buf) { KR_HIP(hipDeviceSynchronize()); KR_HIP(hipFree(h->pred_buf)); h->pred_buf = nullptr; h->pred_bytes = 0; }
+        KR_HIP(hipMalloc(&h->pred_buf, need));
+        h->pred_bytes = need;
+      }
+      pred = static_cast<double*>(h->pred_buf);
+    }
+  }
   for (int64_t t = 0; t < T_steps; ++t) {
     // knode.py:65-66,76-77: before the first step y_prev = y (unless the caller hands over the state before)
     const int64_t ic = ring ? t % 3 : t;
@@ -188,6 +202,7 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
     if (order > h->predictor) order = h->predictor;  // (orders 3..5: persistent kernel only)
     if (order == 2) a.prev2 = t == 1 ? (const T*)prev_init : base + (ring ? (t + 1) % 3 : t - 2) * slot;
     a.pred_order = order;
+    a.pred = pred; a.pred_reset = t == 0; a.pred_has_prev = prev_init != nullptr; a.pred_limit = h->predictor;
     if (tip) { a.tip = (T*)tip + t * 3; a.tip_stride = T_steps * 3; }
     if (status) { a.status = status + t; a.st_stride = T_steps; }
     int rc = launch_step<T>(h, scheme, use_nn, a, s);
@@ -376,6 +391,7 @@ int kr_destroy(kr_handle* h) {
   if (!h) return KR_OK;
   free_mlp(h);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->pred_buf) (void)hipFree(h->pred_buf);
   delete h;
   return KR_OK;
 }

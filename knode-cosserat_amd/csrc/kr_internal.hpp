@@ -54,6 +54,8 @@ struct kr_handle {
   std::vector<void*> mlp_allocs;
   // lazily grown scratch (history fallback, MLP activation spill)
   void* ws = nullptr;
+  void* pred_buf = nullptr;   // predictor images of the one-launch-per-step multiple-shooting path
+  size_t pred_bytes = 0;
   size_t ws_bytes = 0;
   int lds_limit = 160 * 1024;
   int ms_mode = -1;          // multiple-shooting step kernel: -1 auto (by batch size), 0 off, 1 forced
@@ -96,6 +98,9 @@ int launch_unpack50(kr_handle* h, int64_t B, const T* st, const T* m1, const T* 
 template <typename T>
 int launch_tip(kr_handle* h, int64_t B, const T* state, T* tip, hipStream_t s);
 
+// doubles per rod of a predictor image (kr_ms_impl.hpp: MS_PRED_ROWS x 64 lanes)
+constexpr size_t KR_PRED_IMG_DOUBLES = 24 * 64;
+
 template <typename T>
 struct StepArgs {
   int64_t B;
@@ -119,6 +124,12 @@ struct StepArgs {
   int maxit;
   int mode;         // 0 = Newton step, 1 = single residual sweep
   int pred_order;   // initial guess: 0 = caller's G / current state, 1 = linear, 2 = quadratic extrapolation in time
+  // multiple-shooting kernel inside kr_simulate_batch: image of the start-value predictor (MsPred, kr_ms_impl.hpp),
+  // [B][MS_PRED_ROWS][64] doubles, read and rewritten by every launch; nullptr = extrapolate from the states
+  double* pred = nullptr;
+  int pred_reset = 0;     // first step of a simulate call: build the predictor from cur / prev
+  int pred_has_prev = 0;  // ... prev is a real earlier state
+  int pred_limit = 0;     // the handle's "predictor" option
 };
 template <typename T>
 int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s);

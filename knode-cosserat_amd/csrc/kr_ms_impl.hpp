@@ -677,6 +677,214 @@ __device__ __forceinline__ bool ms_base_bc(const T* cold, int r, T& g) {
 }
 
 // ---------------------------------------------------------------------------
+// Start-value predictor of one rod (= one wavefront): time levels of the unknowns (interval-start states,
+// lane l keeps elements l and 64 + l of the MS_P x 19 vector) and what was learned about them.  The
+// persistent kernel keeps it in registers across its time loop; the one-launch-per-step kernel carries it
+// from launch to launch through an image in HBM (kr_simulate_batch owns the buffer).
+// ---------------------------------------------------------------------------
+static_assert(MS_YP == 19, "Xs is indexed as one flat vector by the predictor");
+constexpr int MS_NE = MS_P * 19;
+constexpr int MS_EPL = (MS_NE + WAVE - 1) / WAVE;
+template <typename T>
+struct MsPred {
+  T Hx[MS_EPL][MS_HLEV];  // Hx[q][k]: element lane + 64 q, k steps back
+  // adaptive linear predictor: x(t+1) ~ a0 x(t) + a1 (x(t) - x(t-1)) + a2 (x(t) - 2 x(t-1) + x(t-2)) with the
+  // three coefficients fitted per rod (a = (1, 1, 1) is quadratic extrapolation)
+  double lpa[3];
+  bool lp_have;    // lpa was fitted on the previous step (so it can be tested on this one)
+  bool lp_good;    // ... and predicted this step to better than 1e-3
+  int avail;       // time levels behind the newest one that carry information
+  int next_order;  // extrapolation order of the coming step (MS_ORDER_LP: the linear predictor)
+  T kappa;         // contraction constant handed to ms_newton (MsSolveArgs::kappa)
+};
+constexpr int MS_PRED_ROWS = MS_EPL * MS_HLEV + 8;  // doubles per lane of the HBM image
+static_assert((size_t)MS_PRED_ROWS * WAVE == KR_PRED_IMG_DOUBLES, "kr_internal.hpp sizes the image buffer");
+
+template <typename T>
+__device__ __forceinline__ void ms_pred_init(MsPred<T>& Q, int lane, const MsRole& R, const T* s0, const T* sp,
+                                             bool has_prev, int predictor) {
+#pragma unroll
+  for (int q = 0; q < MS_EPL; ++q) {
+    const int e = lane + q * WAVE;
+    const int i = e < MS_NE ? e / 19 : 0, r = e < MS_NE ? e - i * 19 : 0;
+    const size_t off = (size_t)ms_interval_start(i, R.sbase, R.srem) * KR_SLOTS + ms_slot_of_yrow(r);
+    Q.Hx[q][0] = s0[off];
+#pragma unroll
+    for (int k = 1; k < MS_HLEV; ++k) Q.Hx[q][k] = sp[off];
+  }
+  Q.lpa[0] = Q.lpa[1] = Q.lpa[2] = 1.0;
+  Q.lp_have = Q.lp_good = false;
+  Q.avail = has_prev ? 1 : 0;
+  Q.next_order = Q.avail < predictor ? Q.avail : predictor;
+  if (Q.next_order >= MS_HLEV) Q.next_order = MS_HLEV - 1;
+  Q.kappa = T(0);
+}
+template <typename T>
+__device__ __forceinline__ void ms_pred_save(const MsPred<T>& Q, double* img, int lane) {
+#pragma unroll
+  for (int q = 0; q < MS_EPL; ++q)
+#pragma unroll
+    for (int k = 0; k < MS_HLEV; ++k) img[(q * MS_HLEV + k) * WAVE + lane] = (double)Q.Hx[q][k];
+  double* u = img + MS_EPL * MS_HLEV * WAVE;
+  u[0 * WAVE + lane] = Q.lpa[0]; u[1 * WAVE + lane] = Q.lpa[1]; u[2 * WAVE + lane] = Q.lpa[2];
+  u[3 * WAVE + lane] = (double)Q.kappa;
+  u[4 * WAVE + lane] = (double)Q.avail; u[5 * WAVE + lane] = (double)Q.next_order;
+  u[6 * WAVE + lane] = Q.lp_have ? 1.0 : 0.0; u[7 * WAVE + lane] = Q.lp_good ? 1.0 : 0.0;
+}
+template <typename T>
+__device__ __forceinline__ void ms_pred_load(MsPred<T>& Q, const double* img, int lane) {
+#pragma unroll
+  for (int q = 0; q < MS_EPL; ++q)
+#pragma unroll
+    for (int k = 0; k < MS_HLEV; ++k) Q.Hx[q][k] = (T)img[(q * MS_HLEV + k) * WAVE + lane];
+  const double* u = img + MS_EPL * MS_HLEV * WAVE;
+  Q.lpa[0] = u[0 * WAVE + lane]; Q.lpa[1] = u[1 * WAVE + lane]; Q.lpa[2] = u[2 * WAVE + lane];
+  Q.kappa = (T)u[3 * WAVE + lane];
+  // (uniform values: readfirstlane keeps them, and the control flow that depends on them, scalar)
+  Q.avail = __builtin_amdgcn_readfirstlane((int)u[4 * WAVE + lane]);
+  Q.next_order = __builtin_amdgcn_readfirstlane((int)u[5 * WAVE + lane]);
+  Q.lp_have = __builtin_amdgcn_readfirstlane((int)u[6 * WAVE + lane]) != 0;
+  Q.lp_good = __builtin_amdgcn_readfirstlane((int)u[7 * WAVE + lane]) != 0;
+}
+
+// writes the start values of the coming step into Xs (boundary rows of interval 0 from the cold table)
+template <typename T>
+__device__ __forceinline__ void ms_pred_guess(const MsPred<T>& Q, int order, int lane, const T* cold, T* Xs) {
+#pragma unroll
+      for (int q = 0; q < MS_EPL; ++q) {
+        const int e = lane + q * WAVE;
+        if (e < MS_NE) {
+          const int i = e / 19, r = e - i * 19;
+          T g;
+          if (order == MS_ORDER_LP) {
+            const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+            g = (T)(Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2));
+          } else {
+            g = extrapolate_n<T>(order, Q.Hx[q]);
+          }
+          if (i == 0) {
+            T bc;
+            if (ms_base_bc(cold, r, bc)) g = bc;
+          }
+          Xs[i * MS_YP + r] = g;
+        }
+      }
+}
+
+// after a step: which predictor would have predicted it best (-> Q.next_order), refit the linear
+// predictor, shift the time levels.  `order` is what the step just solved started from.
+template <typename T>
+__device__ __forceinline__ void ms_pred_update(MsPred<T>& Q, int order, int status, int predictor, int lane,
+                                               const T* Xs, MsStamps& stamps) {
+    // ---- extrapolation order of the next step: the one that would have predicted this step best ----
+    // (smooth inputs climb to the highest order; after a jump in the controls the low orders win
+    // until the jump has left the stencil; fresh random controls every step stay at order 0, which
+    // is the reference's warm start, knode.py:89)
+    {
+      // (while the fitted recurrence below is in use and predicts to better than 1e-3 the polynomial orders
+      // are not evaluated at all: their errors would only be compared with a much smaller one)
+      const bool poly_eval = !(order == MS_ORDER_LP && Q.lp_good);
+      float err[MS_HLEV];
+#pragma unroll
+      for (int p = 0; p < MS_HLEV; ++p) err[p] = 0.f;
+      if (poly_eval) {
+#pragma unroll
+        for (int q = 0; q < MS_EPL; ++q) {
+          const int e = lane + q * WAVE;
+          if (e < MS_NE) {
+            const T x = Xs[e];
+#pragma unroll
+            for (int p = 0; p < MS_HLEV; ++p) err[p] = fmaxf(err[p], update_ratio(x - extrapolate_n<T>(p, Q.Hx[q]), x));
+          }
+        }
+      }
+      // The unknowns of a rod driven by smooth inputs follow, over a few steps, a linear recurrence (a constant
+      // plus one dominant oscillation is reproduced exactly by three taps), which predicts far better than
+      // any fixed polynomial when the motion is fast against the time step: weighted least squares over the
+      // MS_P x 19 components for "this step from the previous three", tested on the step after.
+      float err_lp = 0.f;
+      double Sn[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
+#pragma unroll
+      for (int q = 0; q < MS_EPL; ++q) {
+        const int e = lane + q * WAVE;
+        if (e < MS_NE) {
+          const double x = (double)Xs[e];
+          const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+          const double b0 = h0, b1 = h0 - h1, b2 = h0 - 2.0 * h1 + h2;
+          if (Q.lp_have) err_lp = fmaxf(err_lp, update_ratio(x - (Q.lpa[0] * b0 + Q.lpa[1] * b1 + Q.lpa[2] * b2), x));
+          const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
+          const double w0 = b0 * w, w1 = b1 * w, w2 = b2 * w, xw = x * w;
+          Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
+          Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
+        }
+      }
+      const float em_lp = wave_max_nonneg(err_lp);
+      const bool lp_tested = Q.lp_have;
+      Q.lp_have = false;
+      if (predictor >= MS_ORDER_LP && Q.avail >= 2 && status == KR_ST_CONVERGED) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sn[k] = wave_sum_f64(Sn[k]);
+        // (N + lam diag N) a = r + lam diag(N) 1: ridge towards quadratic extrapolation, relative per column
+        const double lam = 1e-12;
+        double a6[3][4] = {{Sn[0] * (1 + lam), Sn[1], Sn[2], Sn[6] + lam * Sn[0]},
+                           {Sn[1], Sn[3] * (1 + lam), Sn[4], Sn[7] + lam * Sn[3]},
+                           {Sn[2], Sn[4], Sn[5] * (1 + lam), Sn[8] + lam * Sn[5]}};
+        // symmetric positive definite: elimination without pivoting
+        const double i0 = fast_rcp(a6[0][0]);
+        const double f1 = a6[1][0] * i0, f2 = a6[2][0] * i0;
+#pragma unroll
+        for (int c = 1; c < 4; ++c) { a6[1][c] -= f1 * a6[0][c]; a6[2][c] -= f2 * a6[0][c]; }
+        const double i1 = fast_rcp(a6[1][1]);
+        const double f3 = a6[2][1] * i1;
+        a6[2][2] -= f3 * a6[1][2]; a6[2][3] -= f3 * a6[1][3];
+        const double x2 = a6[2][3] * fast_rcp(a6[2][2]);
+        const double x1 = (a6[1][3] - a6[1][2] * x2) * i1;
+        const double x0 = (a6[0][3] - a6[0][1] * x1 - a6[0][2] * x2) * i0;
+        if (isfinite(x0) && isfinite(x1) && isfinite(x2) && fabs(x0) < 4.0 && fabs(x1) < 16.0 && fabs(x2) < 64.0) {
+          Q.lpa[0] = x0; Q.lpa[1] = x1; Q.lpa[2] = x2;
+          Q.lp_have = true;
+        }
+      }
+      const int pmax = Q.avail < predictor ? Q.avail : (predictor < MS_HLEV ? predictor : MS_HLEV - 1);  // orders the history supported
+      float em[MS_HLEV];
+#pragma unroll
+      for (int p = 0; p < MS_HLEV; ++p) em[p] = poly_eval ? wave_max_nonneg(err[p]) : 3.0e38f;
+      // best order, at most two above the one just used (chance hits on rough data - where the errors
+      // grow with the order - do not add up to a high order; on smooth data the errors of neighbouring
+      // orders can tie, every second one gains)
+      int nxt = 0;
+      float eb = em[0];
+#pragma unroll
+      for (int p = 1; p < MS_HLEV; ++p)
+        if (p <= pmax && p <= order + 2 && em[p] < eb) { eb = em[p]; nxt = p; }
+      if (nxt == Q.avail && Q.avail + 1 < MS_HLEV && Q.avail + 1 <= predictor && nxt >= order) nxt = Q.avail + 1;  // history still growing
+      if (!poly_eval) nxt = pmax;  // not measured this step: what smooth data would have picked
+      Q.next_order = nxt;
+      // the fitted recurrence takes over when its previous fit predicted this step better than every polynomial
+      Q.lp_good = lp_tested && Q.lp_have && em_lp < 1.0e-3f;
+      if (lp_tested && Q.lp_have && (em_lp < eb || Q.lp_good)) Q.next_order = MS_ORDER_LP;
+#ifdef KR_MS_STAMPS
+      stamps.osum += (unsigned long long)order; stamps.olast = order;
+      for (int p = 0; p < MS_HLEV; ++p) stamps.em[p] = em[p];
+#endif
+      if (status != KR_ST_CONVERGED) {  // start over from the plain warm start
+        Q.next_order = 0;
+        Q.avail = -1;  // becomes 0 below
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MS_EPL; ++q) {
+      const int e = lane + q * WAVE;
+#pragma unroll
+      for (int k = MS_HLEV - 1; k > 0; --k) Q.Hx[q][k] = Q.Hx[q][k - 1];
+      if (e < MS_NE) Q.Hx[q][0] = Xs[e];  // MS_YP == 19: Xs is the same flat vector
+    }
+  if (Q.avail < MS_HLEV - 1) ++Q.avail;
+}
+
+// ---------------------------------------------------------------------------
 // one time step per launch (kr_step_batch, and kr_simulate_batch when the persistent form does not apply)
 // ---------------------------------------------------------------------------
 template <typename T, bool DIAG, int SCHEME, int HS, bool NN>
@@ -699,19 +907,6 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
     const size_t off = rod * rod_elems + (size_t)j * KR_SLOTS;
     build_hist_point<T, HS>(Pc, A.hc1, A.hc2, A.cur + off, A.prev + off, L.hist + (size_t)j * HS);
   }
-  // initial guess: time extrapolation of the previous states
-  for (int e = lane; e < MS_P * 19; e += WAVE) {
-    const int i = e / 19, r = e - i * 19;
-    const int sj = ms_interval_start(i, R.sbase, R.srem);
-    const size_t off = rod * rod_elems + (size_t)sj * KR_SLOTS + ms_slot_of_yrow(r);
-    T g = extrapolate<T>(A.pred_order, A.cur[off], A.prev[off], A.prev2 ? A.prev2[off] : T(0));
-    if (i == 0) {
-      T bc;
-      if (ms_base_bc(L.cold, r, bc)) g = bc;
-      else if (A.pred_order <= 0) g = A.G[rod * 6 + (r - 7)];  // caller's guess unless extrapolated
-    }
-    L.Xs[i * MS_YP + r] = g;
-  }
   SweepCtx<T, HS> C;
   ms_ctx_init<T, HS>(L.cold, L.hist, A.tens + rod * A.tens_stride, C);
   if constexpr (NN) {
@@ -730,10 +925,46 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   S.tip = A.tip ? A.tip + rod * A.tip_stride : nullptr;
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
   S.kappa = T(0);
-  wave_sync();
-  int it;
+  int it, status;
   MsStamps stamps;
-  const int status = ms_newton<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it, stamps);
+  if (A.pred) {
+    // kr_simulate_batch, one launch per step: the predictor of the persistent kernel, carried from launch to
+    // launch through its image in HBM
+    double* img = A.pred + (size_t)rod * MS_PRED_ROWS * WAVE;
+    MsPred<T> Q;
+    if (A.pred_reset) ms_pred_init<T>(Q, lane, R, A.cur + rod * rod_elems, A.prev + rod * rod_elems, A.pred_has_prev != 0, A.pred_limit);
+    else ms_pred_load<T>(Q, img, lane);
+    S.kappa = Q.kappa;
+    int order = Q.next_order;
+    while (true) {
+      ms_pred_guess<T>(Q, order, lane, L.cold, L.Xs);
+      wave_sync();
+      if (order <= 0 && lane < 6) L.Xs[0 * MS_YP + 7 + lane] = A.G[rod * 6 + lane];  // caller's guess (knode.py:67,89)
+      wave_sync();
+      status = ms_newton<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it, stamps);
+      if (status == KR_ST_CONVERGED || order == 0) break;
+      order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
+    }
+    ms_pred_update<T>(Q, order, status, A.pred_limit, lane, L.Xs, stamps);
+    Q.kappa = S.kappa;
+    ms_pred_save<T>(Q, img, lane);
+  } else {
+    // initial guess: time extrapolation of the previous states (kr_step_batch)
+    for (int e = lane; e < MS_P * 19; e += WAVE) {
+      const int i = e / 19, r = e - i * 19;
+      const int sj = ms_interval_start(i, R.sbase, R.srem);
+      const size_t off = rod * rod_elems + (size_t)sj * KR_SLOTS + ms_slot_of_yrow(r);
+      T g = extrapolate<T>(A.pred_order, A.cur[off], A.prev[off], A.prev2 ? A.prev2[off] : T(0));
+      if (i == 0) {
+        T bc;
+        if (ms_base_bc(L.cold, r, bc)) g = bc;
+        else if (A.pred_order <= 0) g = A.G[rod * 6 + (r - 7)];  // caller's guess unless extrapolated
+      }
+      L.Xs[i * MS_YP + r] = g;
+    }
+    wave_sync();
+    status = ms_newton<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it, stamps);
+  }
   if (lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * MS_YP + 7 + lane];
   if (lane == 0) {
     if (A.status) A.status[rod * A.st_stride] = status;
@@ -779,21 +1010,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
       for (int c = 0; c < 12; ++c) regP[q][c] = T(0);
     }
   }
-  // time levels of the unknowns (interval-start states; extrapolated to start Newton), in registers:
-  // lane l keeps elements l and 64 + l of the MS_P x 19 vector
-  static_assert(MS_YP == 19, "Xs is indexed as one flat vector below");
-  constexpr int MS_NE = MS_P * 19;
-  constexpr int MS_EPL = (MS_NE + WAVE - 1) / WAVE;
-  T Hx[MS_EPL][MS_HLEV];
-#pragma unroll
-  for (int q = 0; q < MS_EPL; ++q) {
-    const int e = lane + q * WAVE;
-    const int i = e < MS_NE ? e / 19 : 0, r = e < MS_NE ? e - i * 19 : 0;
-    const size_t off = (size_t)ms_interval_start(i, R.sbase, R.srem) * KR_SLOTS + ms_slot_of_yrow(r);
-    Hx[q][0] = s0[off];
-#pragma unroll
-    for (int k = 1; k < MS_HLEV; ++k) Hx[q][k] = sp[off];
-  }
+  MsPred<T> Q;
+  ms_pred_init<T>(Q, lane, R, s0, sp, A.prev_init != nullptr, A.predictor);
   MsSolveArgs<T> S;
   {
     const T* cl = s0 + (size_t)(N - 1) * KR_SLOTS;
@@ -802,14 +1020,6 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   }
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
   S.kappa = T(0);
-  int avail = A.prev_init ? 1 : 0;  // time levels behind states[0] that carry information
-  int next_order = avail < A.predictor ? avail : A.predictor;  // extrapolation order of the coming step
-  if (next_order >= MS_HLEV) next_order = MS_HLEV - 1;
-  // adaptive linear predictor: x(t+1) ~ a0 x(t) + a1 (x(t) - x(t-1)) + a2 (x(t) - 2 x(t-1) + x(t-2)) with the
-  // three coefficients fitted per rod (a = (1, 1, 1) is quadratic extrapolation)
-  double lpa[3] = {1.0, 1.0, 1.0};
-  bool lp_have = false;  // lpa was fitted on the previous step (so it can be tested on this one)
-  bool lp_good = false;  // ... and predicted this step to better than 1e-3
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];
@@ -848,28 +1058,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     S.out_rod = A.states + inx * A.slot_elems + rod * rod_elems;
     S.tip = A.tip ? A.tip + (rod * A.T_steps + t) * 3 : nullptr;
     // ---- initial guess and solve ---------------------------------------------------
-    int order = next_order;
+    int order = Q.next_order;
     int status, it;
     while (true) {
-#pragma unroll
-      for (int q = 0; q < MS_EPL; ++q) {
-        const int e = lane + q * WAVE;
-        if (e < MS_NE) {
-          const int i = e / 19, r = e - i * 19;
-          T g;
-          if (order == MS_ORDER_LP) {
-            const double h0 = (double)Hx[q][0], h1 = (double)Hx[q][1], h2 = (double)Hx[q][2];
-            g = (T)(lpa[0] * h0 + lpa[1] * (h0 - h1) + lpa[2] * (h0 - 2.0 * h1 + h2));
-          } else {
-            g = extrapolate_n<T>(order, Hx[q]);
-          }
-          if (i == 0) {
-            T bc;
-            if (ms_base_bc(L.cold, r, bc)) g = bc;
-          }
-          L.Xs[i * MS_YP + r] = g;
-        }
-      }
+      ms_pred_guess<T>(Q, order, lane, L.cold, L.Xs);
       wave_sync();
       if (order <= 0 && lane < 6) L.Xs[0 * MS_YP + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
       wave_sync();
@@ -885,114 +1077,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
 #endif
     }
     if (lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
-    // ---- shift the time levels of the unknowns ------------------------------------
-    // ---- extrapolation order of the next step: the one that would have predicted this step best ----
-    // (smooth inputs climb to the highest order; after a jump in the controls the low orders win
-    // until the jump has left the stencil; fresh random controls every step stay at order 0, which
-    // is the reference's warm start, knode.py:89)
-    {
-      // (while the fitted recurrence below is in use and predicts to better than 1e-3 the polynomial orders
-      // are not evaluated at all: their errors would only be compared with a much smaller one)
-      const bool poly_eval = !(order == MS_ORDER_LP && lp_good);
-      float err[MS_HLEV];
-#pragma unroll
-      for (int p = 0; p < MS_HLEV; ++p) err[p] = 0.f;
-      if (poly_eval) {
-#pragma unroll
-        for (int q = 0; q < MS_EPL; ++q) {
-          const int e = lane + q * WAVE;
-          if (e < MS_NE) {
-            const T x = L.Xs[e];
-#pragma unroll
-            for (int p = 0; p < MS_HLEV; ++p) err[p] = fmaxf(err[p], update_ratio(x - extrapolate_n<T>(p, Hx[q]), x));
-          }
-        }
-      }
-      // The unknowns of a rod driven by smooth inputs follow, over a few steps, a linear recurrence (a constant
-      // plus one dominant oscillation is reproduced exactly by three taps), which predicts far better than
-      // any fixed polynomial when the motion is fast against the time step: weighted least squares over the
-      // MS_P x 19 components for "this step from the previous three", tested on the step after.
-      float err_lp = 0.f;
-      double Sn[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
-#pragma unroll
-      for (int q = 0; q < MS_EPL; ++q) {
-        const int e = lane + q * WAVE;
-        if (e < MS_NE) {
-          const double x = (double)L.Xs[e];
-          const double h0 = (double)Hx[q][0], h1 = (double)Hx[q][1], h2 = (double)Hx[q][2];
-          const double b0 = h0, b1 = h0 - h1, b2 = h0 - 2.0 * h1 + h2;
-          if (lp_have) err_lp = fmaxf(err_lp, update_ratio(x - (lpa[0] * b0 + lpa[1] * b1 + lpa[2] * b2), x));
-          const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
-          const double w0 = b0 * w, w1 = b1 * w, w2 = b2 * w, xw = x * w;
-          Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
-          Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
-        }
-      }
-      const float em_lp = wave_max_nonneg(err_lp);
-      const bool lp_tested = lp_have;
-      lp_have = false;
-      if (A.predictor >= MS_ORDER_LP && avail >= 2 && status == KR_ST_CONVERGED) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Sn[k] = wave_sum_f64(Sn[k]);
-        // (N + lam diag N) a = r + lam diag(N) 1: ridge towards quadratic extrapolation, relative per column
-        const double lam = 1e-12;
-        double a6[3][4] = {{Sn[0] * (1 + lam), Sn[1], Sn[2], Sn[6] + lam * Sn[0]},
-                           {Sn[1], Sn[3] * (1 + lam), Sn[4], Sn[7] + lam * Sn[3]},
-                           {Sn[2], Sn[4], Sn[5] * (1 + lam), Sn[8] + lam * Sn[5]}};
-        // symmetric positive definite: elimination without pivoting
-        const double i0 = fast_rcp(a6[0][0]);
-        const double f1 = a6[1][0] * i0, f2 = a6[2][0] * i0;
-#pragma unroll
-        for (int c = 1; c < 4; ++c) { a6[1][c] -= f1 * a6[0][c]; a6[2][c] -= f2 * a6[0][c]; }
-        const double i1 = fast_rcp(a6[1][1]);
-        const double f3 = a6[2][1] * i1;
-        a6[2][2] -= f3 * a6[1][2]; a6[2][3] -= f3 * a6[1][3];
-        const double x2 = a6[2][3] * fast_rcp(a6[2][2]);
-        const double x1 = (a6[1][3] - a6[1][2] * x2) * i1;
-        const double x0 = (a6[0][3] - a6[0][1] * x1 - a6[0][2] * x2) * i0;
-        if (isfinite(x0) && isfinite(x1) && isfinite(x2) && fabs(x0) < 4.0 && fabs(x1) < 16.0 && fabs(x2) < 64.0) {
-          lpa[0] = x0; lpa[1] = x1; lpa[2] = x2;
-          lp_have = true;
-        }
-      }
-      const int pmax = avail < A.predictor ? avail : (A.predictor < MS_HLEV ? A.predictor : MS_HLEV - 1);  // orders the history supported
-      float em[MS_HLEV];
-#pragma unroll
-      for (int p = 0; p < MS_HLEV; ++p) em[p] = poly_eval ? wave_max_nonneg(err[p]) : 3.0e38f;
-      // best order, at most two above the one just used (chance hits on rough data - where the errors
-      // grow with the order - do not add up to a high order; on smooth data the errors of neighbouring
-      // orders can tie, every second one gains)
-      int nxt = 0;
-      float eb = em[0];
-#pragma unroll
-      for (int p = 1; p < MS_HLEV; ++p)
-        if (p <= pmax && p <= order + 2 && em[p] < eb) { eb = em[p]; nxt = p; }
-      if (nxt == avail && avail + 1 < MS_HLEV && avail + 1 <= A.predictor && nxt >= order) nxt = avail + 1;  // history still growing
-      if (!poly_eval) nxt = pmax;  // not measured this step: what smooth data would have picked
-      next_order = nxt;
-      // the fitted recurrence takes over when its previous fit predicted this step better than every polynomial
-      lp_good = lp_tested && lp_have && em_lp < 1.0e-3f;
-      if (lp_tested && lp_have && (em_lp < eb || lp_good)) next_order = MS_ORDER_LP;
-#ifdef KR_MS_STAMPS
-      stamps.osum += (unsigned long long)order; stamps.olast = order;
-      for (int p = 0; p < MS_HLEV; ++p) stamps.em[p] = em[p];
-#endif
-      if (status != KR_ST_CONVERGED) {  // start over from the plain warm start
-        next_order = 0;
-        avail = -1;  // becomes 0 below
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < MS_EPL; ++q) {
-      const int e = lane + q * WAVE;
-#pragma unroll
-      for (int k = MS_HLEV - 1; k > 0; --k) Hx[q][k] = Hx[q][k - 1];
-      if (e < MS_NE) Hx[q][0] = L.Xs[e];  // MS_YP == 19: Xs is the same flat vector
-    }
+    ms_pred_update<T>(Q, order, status, A.predictor, lane, L.Xs, stamps);
     if (lane < 6) Gguess = L.Xs[0 * MS_YP + 7 + lane];
-    if (avail < MS_HLEV - 1) ++avail;
     wave_sync();
   }
   if (lane < 6) A.G[rod * 6 + lane] = Gguess;

@@ -87,13 +87,14 @@ for W, b, a in zip(mlp.weights, mlp.biases, mlp.acts):
 rr.nn_model, rr.param_ls, rr.nn_path = model, params, "x"
 h = rr._native()
 for dt in (torch.float64, torch.float32):
-    ctl = torch.as_tensor(orc.batch_sine_controls(1024, 12, rr.del_t, 1235), device=dev).to(dt).contiguous()
+    # one call (the start-value predictor lives for the length of a kr_simulate_batch call); 60 steps
+    TS = 60
+    ctl = torch.as_tensor(orc.batch_sine_controls(1024, TS, rr.del_t, 1235), device=dev).to(dt).contiguous()
     st = h.new_state(1024, dt, n_slots=3); h.init_straight(st[0]); Gs = torch.zeros((1024, 6), dtype=dt, device=dev)
-    status = torch.zeros((1024, 6), dtype=torch.int32, device=dev)
-    h.simulate(ctl[:, :6].contiguous(), st, Gs, ring=True, use_nn=True)
+    status = torch.zeros((1024, TS), dtype=torch.int32, device=dev)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    h.simulate(ctl[:, 6:].contiguous(), st, Gs, ring=True, use_nn=True, status=status, prev_init=st[2])
-    torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 6
+    h.simulate(ctl, st, Gs, ring=True, use_nn=True, status=status)
+    torch.cuda.synchronize(); el = (time.perf_counter() - t0) / TS
     print(f"      forward sim, MLP inside every sweep, {str(dt):14s}: {el*1e3:6.3f} ms/step -> {1024/el/1e3:7.1f} k rod-steps/s (unconverged {int((status!=0).sum())})")
 
 print("cfg4  training loop shard: 512 trajectories per GPU (4096 over 8), train_len 30, 28->512->25")
