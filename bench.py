@@ -164,6 +164,11 @@ def main():
         torch.cuda.synchronize()
     del scratch
 
+    # the W warm-up steps and the K timed steps are one trajectory advanced by two calls: the second call
+    # resumes the start-value predictor of the first (option "keep_predictor"), so that a short timed region
+    # is as representative of the steady state as a long one
+    h.set_option("keep_predictor", 0)
+    h.set_option("keep_predictor", 1)
     if W:
         h.simulate(ctl_w, states, G, ring=True)
     h.set_option("persistent", persistent_default)

@@ -123,6 +123,11 @@ int kr_destroy(kr_handle* h);
  *   "ms_batch_limit" auto mode uses it when B <= limit (default 2048)
  *   "persistent"     1 (default) / 0: kr_simulate_batch runs all steps in one launch when the
  *                    multiple-shooting kernel applies
+ *   "keep_predictor" 0 (default) / 1: kr_simulate_batch leaves the state of its start-value predictor behind
+ *                    and the next call with the same batch size resumes from it - for a simulation that is
+ *                    advanced by several calls, each continuing where the previous one stopped
+ *                    (states[0] of a call = the last state of the one before).  Setting it to 0 drops
+ *                    the stored state.
  *   "predictor"      0..8: how kr_simulate_batch may form the initial guess of each step (default 8;
  *                    0 = the reference's warm start).  1..7: highest order of polynomial time
  *                    extrapolation; the persistent kernel picks, rod by rod and step by step, the

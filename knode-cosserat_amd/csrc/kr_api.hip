@@ -153,6 +153,17 @@ static StepArgs<T> make_args(const kr_handle* h, int64_t B, const void* prev, co
   return a;
 }
 
+static int ensure_pred(kr_handle* h, int64_t B) {
+  const size_t need = (size_t)B * KR_PRED_IMG_DOUBLES * sizeof(double);
+  if (need > h->pred_bytes) {
+    if (h->pred_buf) { KR_HIP(hipDeviceSynchronize()); KR_HIP(hipFree(h->pred_buf)); h->pred_buf = nullptr; h->pred_bytes = 0; }
+    KR_HIP(hipMalloc(&h->pred_buf, need));
+    h->pred_bytes = need;
+    h->pred_valid_B = 0;
+  }
+  return KR_OK;
+}
+
 template <typename T>
 static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, const void* ctl, void* states, int ring,
                          void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn,
@@ -168,9 +179,17 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
     sa.tol = a0.tol; sa.tolA = a0.tolA; sa.fd_eps = a0.fd_eps; sa.hc1 = a0.hc1; sa.hc2 = a0.hc2;
     sa.maxit = a0.maxit; sa.predictor = h->predictor;
     sa.dbg = static_cast<unsigned long long*>(h->dbg);
+    sa.pred_io = nullptr; sa.pred_load = 0;
+    if (h->keep_predictor && (size_t)B * KR_PRED_IMG_DOUBLES * sizeof(double) <= ((size_t)1 << 30)) {
+      int rcp = ensure_pred(h, B);
+      if (rcp) return rcp;
+      sa.pred_io = static_cast<double*>(h->pred_buf);
+      sa.pred_load = h->pred_valid_B == B;
+    }
     const int rc = launch_sim_persistent<T>(h, scheme, use_nn, sa, s);
     if (rc != 1) {
       h->last_sim_path = 2;
+      if (rc == KR_OK && sa.pred_io) h->pred_valid_B = B;
       return rc;
     }
   }
@@ -181,14 +200,12 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
   if (h->predictor > 2 && h->ms_mode != 0 && (h->ms_mode == 1 || B <= (int64_t)h->ms_batch_limit)) {
     const size_t need = (size_t)B * KR_PRED_IMG_DOUBLES * sizeof(double);
     if (need <= ((size_t)1 << 30)) {
-      if (need > h->pred_bytes) {
-        if (h->pred_buf) { KR_HIP(hipDeviceSynchronize()); KR_HIP(hipFree(h->pred_buf)); h->pred_buf = nullptr; h->pred_bytes = 0; }
-        KR_HIP(hipMalloc(&h->pred_buf, need));
-        h->pred_bytes = need;
-      }
+      int rcp = ensure_pred(h, B);
+      if (rcp) return rcp;
       pred = static_cast<double*>(h->pred_buf);
     }
   }
+  const bool resume = pred && h->keep_predictor && h->pred_valid_B == B;
   for (int64_t t = 0; t < T_steps; ++t) {
     // knode.py:65-66,76-77: before the first step y_prev = y (unless the caller hands over the state before)
     const int64_t ic = ring ? t % 3 : t;
@@ -202,12 +219,14 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
     if (order > h->predictor) order = h->predictor;  // (orders 3..5: persistent kernel only)
     if (order == 2) a.prev2 = t == 1 ? (const T*)prev_init : base + (ring ? (t + 1) % 3 : t - 2) * slot;
     a.pred_order = order;
-    a.pred = pred; a.pred_reset = t == 0; a.pred_has_prev = prev_init != nullptr; a.pred_limit = h->predictor;
+    a.pred = pred; a.pred_reset = t == 0 && !resume; a.pred_has_prev = prev_init != nullptr; a.pred_limit = h->predictor;
     if (tip) { a.tip = (T*)tip + t * 3; a.tip_stride = T_steps * 3; }
     if (status) { a.status = status + t; a.st_stride = T_steps; }
     int rc = launch_step<T>(h, scheme, use_nn, a, s);
     if (rc) return rc;
   }
+  // the image is current only if the multiple-shooting kernel took the steps (launch_step decides)
+  if (pred) h->pred_valid_B = (T_steps > 0 && h->last_sim_path == 1) ? B : (T_steps > 0 ? 0 : h->pred_valid_B);
   return KR_OK;
 }
 
@@ -348,6 +367,9 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
     h->ms_batch_limit = value;
   } else if (n == "persistent") {
     h->persistent = value ? 1 : 0;
+  } else if (n == "keep_predictor") {
+    h->keep_predictor = value ? 1 : 0;
+    if (!value) h->pred_valid_B = 0;
   } else if (n == "fused_mlp") {
     h->fused_mlp = value ? 1 : 0;
   } else if (n == "mfma_mlp") {
@@ -370,6 +392,7 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   if (n == "ms_mode") *value = h->ms_mode;
   else if (n == "ms_batch_limit") *value = h->ms_batch_limit;
   else if (n == "persistent") *value = h->persistent;
+  else if (n == "keep_predictor") *value = h->keep_predictor;
   else if (n == "mfma_mlp") *value = h->mfma_mlp;
   else if (n == "fused_mlp") *value = h->fused_mlp;
   else if (n == "predictor") *value = h->predictor;

@@ -56,6 +56,8 @@ struct kr_handle {
   void* ws = nullptr;
   void* pred_buf = nullptr;   // predictor images of the one-launch-per-step multiple-shooting path
   size_t pred_bytes = 0;
+  int keep_predictor = 0;     // kr_simulate_batch resumes from / leaves behind the predictor image (option)
+  int64_t pred_valid_B = 0;   // batch size the image in pred_buf was written for (0: none)
   size_t ws_bytes = 0;
   int lds_limit = 160 * 1024;
   int ms_mode = -1;          // multiple-shooting step kernel: -1 auto (by batch size), 0 off, 1 forced
@@ -148,7 +150,9 @@ struct SimArgs {
   int32_t* status;      // [B][T] nullable
   T tol, tolA, fd_eps, hc1, hc2;
   int maxit, predictor;
-  unsigned long long* dbg;  // diagnostic builds (-DKR_MS_STAMPS): [B][8] cycle counters, else unused
+  unsigned long long* dbg;  // diagnostic builds (-DKR_MS_STAMPS): [B][24] cycle counters, else unused
+  double* pred_io;          // predictor image [B][KR_PRED_IMG_DOUBLES]: saved at the end (nullable)
+  int pred_load;            // ... and loaded at the start instead of building the predictor from the states
 };
 
 // returns 1 when the persistent form does not apply

@@ -1011,7 +1011,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     }
   }
   MsPred<T> Q;
-  ms_pred_init<T>(Q, lane, R, s0, sp, A.prev_init != nullptr, A.predictor);
+  double* img = A.pred_io ? A.pred_io + (size_t)rod * MS_PRED_ROWS * WAVE : nullptr;
+  if (img && A.pred_load) ms_pred_load<T>(Q, img, lane);
+  else ms_pred_init<T>(Q, lane, R, s0, sp, A.prev_init != nullptr, A.predictor);
   MsSolveArgs<T> S;
   {
     const T* cl = s0 + (size_t)(N - 1) * KR_SLOTS;
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     S.ulast = {cl[SL_U], cl[SL_U + 1], cl[SL_U + 2]};
   }
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
-  S.kappa = T(0);
+  S.kappa = Q.kappa;
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];
@@ -1082,6 +1084,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     wave_sync();
   }
   if (lane < 6) A.G[rod * 6 + lane] = Gguess;
+  if (img) {
+    Q.kappa = S.kappa;
+    ms_pred_save<T>(Q, img, lane);
+  }
 #ifdef KR_MS_STAMPS
   if (lane == 0 && A.dbg) {
     unsigned long long te;

@@ -423,3 +423,39 @@ def test_simulate_legacy_preset(torch_cuda):
     want = orc.simulate(P.derived(), ctl, solver="fsolve")
     got = simulate(r, ctl)
     assert rel_l2(got[:, :25], want[:, :25]) < 1e-8
+
+
+def test_keep_predictor_chunked_calls(torch_cuda, shooting_mode):
+    """A trajectory advanced by several kr_simulate_batch calls with "keep_predictor" on gives the states of one
+    long call (the predictor only chooses where Newton starts), for both launch forms and when they alternate."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    r = make_robot(None, 40)
+    h = r._native()
+    B, T = 8, 48
+    dev = "cuda:0"
+    ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 21), device=dev).contiguous()
+
+    def run(chunks, keep, flip=False):
+        h.set_option("keep_predictor", 0)
+        h.set_option("keep_predictor", keep)
+        st = h.new_state(B, torch.float64, n_slots=T + 1)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=torch.float64, device=dev)
+        status = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+        t0 = 0
+        for k, n in enumerate(chunks):
+            if flip:
+                h.set_option("persistent", k % 2)
+            h.simulate(ctl[:, t0:t0 + n].contiguous(), st[t0:], G, status=status[:, t0:t0 + n].contiguous(),
+                       prev_init=st[t0 - 1] if t0 else None)
+            t0 += n
+        torch.cuda.synchronize()
+        h.set_option("keep_predictor", 0)
+        return st[..., :25].cpu().numpy()
+
+    one = run([T], 0)
+    for chunks, keep, flip in (([16, 16, 16], 1, False), ([16, 16, 16], 0, False), ([7, 20, 21], 1, True)):
+        got = run(chunks, keep, flip)
+        assert rel_l2(got[T], one[T]) < 1e-7 and rel_l2(got[17], one[17]) < 1e-7
+    h.set_option("persistent", 1 if shooting_mode == "persistent" else 0)
