@@ -123,6 +123,7 @@ int kr_destroy(kr_handle* h);
  *   "ms_batch_limit" auto mode uses it when B <= limit (default 2048)
  *   "persistent"     1 (default) / 0: kr_simulate_batch runs all steps in one launch when the
  *                    multiple-shooting kernel applies
+ *   "mlp_grad_accumulate" 0 (default) / 1: see kr_adam_step
  *   "keep_predictor" 0 (default) / 1: kr_simulate_batch leaves the state of its start-value predictor behind
  *                    and the next call with the same batch size resumes from it - for a simulation that is
  *                    advanced by several calls, each continuing where the previous one stopped
@@ -266,6 +267,16 @@ int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, 
  * dout[row][32] = d loss / d out (columns 25..31 zero).  out is [rows][32]. */
 int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const float* out, const float* target,
                     const int32_t* idx, double denom, float* pred, float* loss, float* dout, void* stream);
+
+/* torch.optim.Adam (amsgrad off) on one flat fp32 parameter vector - physics_train.py:199,289-296 - followed by
+ * the reference's clamp (physics_train.py:299-304: params = max(params, lower), lower[i] = 0 for weight-matrix
+ * entries and -inf for biases; NULL = no clamp) and by zeroing grads[0 .. n_zero) for the next epoch
+ * (n_zero >= n covers trailing slots of the same buffer, e.g. the loss).  step = 1, 2, ... (bias correction).
+ * With the option "mlp_grad_accumulate" = 1, kr_mlp_backward and kr_loss_rows_fwd_bwd add into dW / db / loss
+ * instead of zeroing them first, so that this call is the only one that touches the buffers between epochs. */
+int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                 const float* lower, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 int64_t step, int64_t n_zero, void* stream);
 
 /* The same loss against pre-gathered targets: the states a training set is scored against never
  * change between epochs, so kr_gather_targets extracts rows[S*K][25] once (y rows at column idx[k],

@@ -85,8 +85,9 @@ class _MlpFunction(torch.autograd.Function):
         n = len(acts)
         Q = x.shape[0]
         g = grad_out.contiguous().float()
-        dW = [torch.empty_like(w) for w in Ws]
-        db = [torch.empty(w.shape[0], dtype=torch.float32, device=x.device) for w in Ws]
+        # zero-filled: with the handle option "mlp_grad_accumulate" (set by KnodeTrainer) the library adds into them
+        dW = [torch.zeros_like(w) for w in Ws]
+        db = [torch.zeros(w.shape[0], dtype=torch.float32, device=x.device) for w in Ws]
         dims_c = (C.c_int32 * (n + 1))(*dims)
         acts_c = (C.c_int32 * n)(*acts)
         Wp = (C.c_void_p * n)(*[w.data_ptr() for w in Ws])

@@ -367,6 +367,8 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
     h->ms_batch_limit = value;
   } else if (n == "persistent") {
     h->persistent = value ? 1 : 0;
+  } else if (n == "mlp_grad_accumulate") {
+    h->grad_accumulate = value ? 1 : 0;
   } else if (n == "keep_predictor") {
     h->keep_predictor = value ? 1 : 0;
     if (!value) h->pred_valid_B = 0;
@@ -393,6 +395,7 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   else if (n == "ms_batch_limit") *value = h->ms_batch_limit;
   else if (n == "persistent") *value = h->persistent;
   else if (n == "keep_predictor") *value = h->keep_predictor;
+  else if (n == "mlp_grad_accumulate") *value = h->grad_accumulate;
   else if (n == "mfma_mlp") *value = h->mfma_mlp;
   else if (n == "fused_mlp") *value = h->fused_mlp;
   else if (n == "predictor") *value = h->predictor;

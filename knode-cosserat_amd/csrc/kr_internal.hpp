@@ -56,6 +56,7 @@ struct kr_handle {
   void* ws = nullptr;
   void* pred_buf = nullptr;   // predictor images of the one-launch-per-step multiple-shooting path
   size_t pred_bytes = 0;
+  int grad_accumulate = 0;    // kr_mlp_backward / kr_loss_rows_fwd_bwd add to dW, db, loss instead of zeroing them first
   int keep_predictor = 0;     // kr_simulate_batch resumes from / leaves behind the predictor image (option)
   int64_t pred_valid_B = 0;   // batch size the image in pred_buf was written for (0: none)
   size_t ws_bytes = 0;

@@ -15,6 +15,8 @@
 // The physics has no trainable parameter and the reference feeds ground-truth columns to every
 // segment ("y and z are not updated here", cosserat_ode_torch.py:391), so d loss / d theta flows only
 // through the MLP output: training = elementwise physics (forward only) + MLP forward/backward.
+#include <cmath>
+
 #include "kr_internal.hpp"
 
 namespace kr {
@@ -390,6 +392,31 @@ __global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, i
   if (threadIdx.x == 0) atomicAdd(loss, red[0]);
 }
 
+
+// torch.optim.Adam (no amsgrad) on one flat parameter vector, followed by the reference's weight clamp
+// (physics_train.py:299-304: p = max(p, lower), lower = 0 for weight matrices, -inf for biases) and by the
+// zeroing of the gradient buffer (and its trailing loss slot) for the next epoch: one launch per epoch
+// instead of torch's three multi-tensor kernels, one clamp per layer and seven memsets.
+__global__ void adam_kernel(int64_t n, int64_t n_zero, float* __restrict__ p, float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, const float* __restrict__ lower,
+                            float step_size, float b1, float b2, float inv_sqrt_bc2, float eps, float wd) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n) {
+      float pi = p[i];
+      float gi = g[i];
+      if (wd != 0.f) gi = fmaf(wd, pi, gi);
+      const float mi = fmaf(b1, m[i], (1.f - b1) * gi);           // exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      m[i] = mi;
+      v[i] = vi;
+      const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;         // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+      pi -= step_size * (mi / denom);                             // param.addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
+      if (lower) pi = fmaxf(pi, lower[i]);
+      p[i] = pi;
+    }
+    g[i] = 0.f;
+  }
+}
 }  // namespace kr
 
 using namespace kr;
@@ -520,8 +547,10 @@ int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   for (int k = 0; k < n_layers; ++k) {
     KR_CHECK_PTR(dW[k]); KR_CHECK_PTR(db[k]);
-    KR_HIP(hipMemsetAsync(dW[k], 0, sizeof(float) * dims[k] * dims[k + 1], s));
-    KR_HIP(hipMemsetAsync(db[k], 0, sizeof(float) * dims[k + 1], s));
+    if (!h->grad_accumulate) {  // option "mlp_grad_accumulate": the caller keeps the buffers zeroed (kr_adam_step does)
+      KR_HIP(hipMemsetAsync(dW[k], 0, sizeof(float) * dims[k] * dims[k + 1], s));
+      KR_HIP(hipMemsetAsync(db[k], 0, sizeof(float) * dims[k + 1], s));
+    }
   }
   if (Q == 0) return KR_OK;
   KR_CHECK_PTR(x); KR_CHECK_PTR(dout);
@@ -624,7 +653,7 @@ int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, cons
   if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
   KR_CHECK_PTR(loss);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  KR_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+  if (!h->grad_accumulate) KR_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
   if (S == 0 || K == 0) return KR_OK;
   KR_CHECK_PTR(base); KR_CHECK_PTR(out); KR_CHECK_PTR(target_rows); KR_CHECK_PTR(dout);
   if (!(denom > 0)) { set_error("denom must be positive"); return KR_E_ARG; }
@@ -637,4 +666,23 @@ int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, cons
   return KR_OK;
 }
 
+
+int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                 const float* lower, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 int64_t step, int64_t n_zero, void* stream) {
+  KR_CHECK_H(h);
+  if (n < 0 || n_zero < n || step < 1) { set_error("kr_adam_step: need n >= 0, n_zero >= n, step >= 1"); return KR_E_ARG; }
+  if (n_zero == 0) return KR_OK;
+  KR_CHECK_PTR(grads);
+  if (n) { KR_CHECK_PTR(params); KR_CHECK_PTR(exp_avg); KR_CHECK_PTR(exp_avg_sq); }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+  int grid = (int)((n_zero + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(kr::adam_kernel, dim3(grid), dim3(256), 0, s, n, n_zero, params, grads, exp_avg, exp_avg_sq, lower,
+                     (float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 / std::sqrt(bc2)), (float)eps,
+                     (float)weight_decay);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
 }  // extern "C"

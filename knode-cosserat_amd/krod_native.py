@@ -84,6 +84,8 @@ _PROTOS = {
     "kr_mlp_backward": (_int, [_vp, _i64, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), _vp, _int, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "kr_loss_fwd_bwd": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "kr_gather_targets": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "kr_adam_step": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double,
+                            C.c_double, _i64, _i64, _vp]),
     "kr_loss_rows_fwd_bwd": (_int, [_vp, _i64, _int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)

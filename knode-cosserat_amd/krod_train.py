@@ -72,8 +72,9 @@ class KnodeTrainer:
     """
 
     def __init__(self, robot, trajs, controls, key_pt_idx, lr=1e-2, weight_decay=0.0, clamp_weights=True,
-                 patience=80, factor=0.5, group=None, keep_pred=True):
+                 patience=80, factor=0.5, group=None, keep_pred=True, native_adam=True):
         self.robot = robot
+        self.native_adam = native_adam  # Adam + clamp + gradient zeroing as ONE kernel (kr_adam_step)
         self.keep_pred = keep_pred  # write the predictions of every epoch (needed only by predictions())
         self.group = group
         self.clamp_weights = clamp_weights
@@ -131,7 +132,31 @@ class KnodeTrainer:
         self.out = torch.zeros((max(Q, 1), 32), dtype=torch.float32, device=dev)
         self.dout = torch.zeros((max(Q, 1), 32), dtype=torch.float32, device=dev)
         self.pred = torch.zeros((max(Q, 1), 25), dtype=torch.float32, device=dev)
-        self.optimizer = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay)
+        self.weight_decay = float(weight_decay)
+        if native_adam:
+            # parameters become views of one flat buffer (same layout as the gradient bucket), Adam's moments
+            # live beside it; torch keeps only the learning-rate schedule (ReduceLROnPlateau on a stand-in group)
+            n = sum(self.bucket.sizes)
+            self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+            self.lower = torch.full((n,), float("-inf"), dtype=torch.float32, device=dev)
+            off = 0
+            for k, (p, sz) in enumerate(zip(self.params, self.bucket.sizes)):
+                view = self.flat_p[off:off + sz].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                if clamp_weights and k % 2 == 0:
+                    self.lower[off:off + sz] = 0.0
+                off += sz
+            self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.adam_step = 0
+            self.betas, self.adam_eps = (0.9, 0.999), 1e-8
+            self._lr_holder = torch.nn.Parameter(torch.zeros(1, device=dev))
+            self.optimizer = torch.optim.SGD([self._lr_holder], lr=lr)  # carries lr for the scheduler only
+            h.set_option("mlp_grad_accumulate", 1)
+            self.bucket.flat.zero_()
+        else:
+            self.optimizer = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", patience=patience,
                                                                     factor=factor)
 
@@ -160,19 +185,33 @@ class KnodeTrainer:
         self.bucket.all_reduce(self.group)
         return self.bucket.loss
 
+    def apply_update(self):
+        """Adam + clamp on the gradients loss_and_grads() left in the bucket (physics_train.py:289-304)."""
+        if self.native_adam:
+            h = self.h
+            self.adam_step += 1
+            n = self.flat_p.numel()
+            kn.check(h.lib.kr_adam_step(h._h, n, kn._ptr(self.flat_p), kn._ptr(self.bucket.flat), kn._ptr(self.exp_avg),
+                                        kn._ptr(self.exp_avg_sq), kn._ptr(self.lower) if self.clamp_weights else None,
+                                        float(self.optimizer.param_groups[0]["lr"]), self.betas[0], self.betas[1],
+                                        self.adam_eps, self.weight_decay, self.adam_step, n + 1, kn._stream()))
+        else:
+            self.optimizer.step()
+            if self.clamp_weights:  # physics_train.py:299-304 - hits every weight matrix (SURVEY section 7)
+                with torch.no_grad():
+                    for k in range(self.n):
+                        self.params[2 * k].clamp_(min=0)
+
     def step(self, sync_loss=True):
         """One epoch of physics_train.py: returns the loss (float if sync_loss)."""
         loss = self.loss_and_grads()
-        self.optimizer.step()
         if sync_loss:
-            val = float(loss.item())
-            self.scheduler.step(val)
+            val = float(loss.item())  # before the update: the native Adam kernel also clears the loss slot
         else:
-            val = loss
-        if self.clamp_weights:  # physics_train.py:299-304 - hits every weight matrix (SURVEY section 7)
-            with torch.no_grad():
-                for k in range(self.n):
-                    self.params[2 * k].clamp_(min=0)
+            val = loss.clone() if self.native_adam else loss
+        self.apply_update()
+        if sync_loss:
+            self.scheduler.step(val)
         return val
 
     def predictions(self):

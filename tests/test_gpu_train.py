@@ -134,10 +134,8 @@ def test_fused_trainer(torch_cuda, path, kp):
     assert rel_l2(pred, ref_pred) < 1e-6
     for i, p in enumerate(rob.nn_models.parameters()):
         assert rel_l2(p.grad.cpu().numpy(), g[f"{path}_grad{i}"]) < 2e-4
-    tr.optimizer.step()
-    with torch.no_grad():
-        for k in range(tr.n):
-            tr.params[2 * k].clamp_(min=0)
+    tr.apply_update()  # kr_adam_step: Adam + clamp + gradient zeroing in one launch
+    assert float(tr.bucket.flat.abs().max()) == 0.0
     for i, p in enumerate(rob.nn_models.parameters()):
         assert np.mean(np.abs(p.detach().cpu().numpy() - g[f"{path}_post{i}"]) < 2e-4) > 0.995
     # a few more epochs must reduce the loss
@@ -145,6 +143,25 @@ def test_fused_trainer(torch_cuda, path, kp):
     for _ in range(20):
         l1 = tr.step()
     assert l1 < l0
+
+
+def test_native_adam_matches_torch(torch_cuda):
+    """kr_adam_step against torch.optim.Adam + clamp over several epochs on the same data, incl. weight decay."""
+    torch = torch_cuda
+    from krod_train import KnodeTrainer
+    g = load_golden("train_step")
+    traj = torch.tensor(g["traj"], device=DEV)[None]
+    controls = torch.tensor(g["controls"], device=DEV)[None]
+    for wd in (0.0, 1e-3):
+        robs = [make_robot(torch, g), make_robot(torch, g)]
+        trs = [KnodeTrainer(robs[0], traj, controls, [3, 5, 7, 9], weight_decay=wd, native_adam=True),
+               KnodeTrainer(robs[1], traj, controls, [3, 5, 7, 9], weight_decay=wd, native_adam=False)]
+        for _ in range(12):
+            la = trs[0].step()
+            lb = trs[1].step()
+            assert abs(la - lb) <= 1e-4 * abs(lb)
+        for pa, pb in zip(robs[0].nn_models.parameters(), robs[1].nn_models.parameters()):
+            assert rel_l2(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 1e-4
 
 
 def test_no_nn_self_consistency(torch_cuda):
