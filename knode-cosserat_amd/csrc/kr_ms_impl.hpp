@@ -190,17 +190,25 @@ __device__ __forceinline__ V3<T> cold_matvec(const T* A, V3<T> x) {
   return {A[0] * x.x + A[1] * x.y + A[2] * x.z, A[3] * x.x + A[4] * x.y + A[5] * x.z,
           A[6] * x.x + A[7] * x.y + A[8] * x.z};
 }
-// hist_derive with the matrices read from the cold table
-template <typename T>
+// hist_derive with the matrices read from the cold table (DIAG: only their diagonals, like ode_eval)
+template <typename T, bool DIAG>
 __device__ __forceinline__ void hist_derive_cold(const T* cold, RodHist<T>& h) {
-  V3<T> bv = cold_matvec(cold + CD_BSE, h.vh);
-  V3<T> t{cold[CD_KSEV] - bv.x, cold[CD_KSEV + 1] - bv.y, cold[CD_KSEV + 2] - bv.z};
-  h.av = cold_matvec(cold + CD_KSEI, t);
-  V3<T> bu = cold_matvec(cold + CD_BBT, h.uh);
-  V3<T> t2 = cold_matvec(cold + CD_KBTI, bu);
-  h.au = {-t2.x, -t2.y, -t2.z};
+  if constexpr (DIAG) {
+    h.av = {cold[CD_KSEI + 0] * (cold[CD_KSEV + 0] - cold[CD_BSE + 0] * h.vh.x),
+            cold[CD_KSEI + 4] * (cold[CD_KSEV + 1] - cold[CD_BSE + 4] * h.vh.y),
+            cold[CD_KSEI + 8] * (cold[CD_KSEV + 2] - cold[CD_BSE + 8] * h.vh.z)};
+    h.au = {-cold[CD_KBTI + 0] * (cold[CD_BBT + 0] * h.uh.x), -cold[CD_KBTI + 4] * (cold[CD_BBT + 4] * h.uh.y),
+            -cold[CD_KBTI + 8] * (cold[CD_BBT + 8] * h.uh.z)};
+  } else {
+    V3<T> bv = cold_matvec(cold + CD_BSE, h.vh);
+    V3<T> t{cold[CD_KSEV] - bv.x, cold[CD_KSEV + 1] - bv.y, cold[CD_KSEV + 2] - bv.z};
+    h.av = cold_matvec(cold + CD_KSEI, t);
+    V3<T> bu = cold_matvec(cold + CD_BBT, h.uh);
+    V3<T> t2 = cold_matvec(cold + CD_KBTI, bu);
+    h.au = {-t2.x, -t2.y, -t2.z};
+  }
 }
-template <typename T, int HS>
+template <typename T, int HS, bool DIAG>
 __device__ __forceinline__ void build_hist_cold(const T* cold, T hc1, T hc2, const T (&cv)[12], const T (&pv)[12],
                                                 T* dst) {
   T hv[HS];
@@ -211,7 +219,7 @@ __device__ __forceinline__ void build_hist_cold(const T* cold, T hc1, T hc2, con
   h.wh = {hv[3], hv[4], hv[5]};
   h.vh = {hv[6], hv[7], hv[8]};
   h.uh = {hv[9], hv[10], hv[11]};
-  hist_derive_cold(cold, h);
+  hist_derive_cold<T, DIAG>(cold, h);
   hv[12] = h.av.x; hv[13] = h.av.y; hv[14] = h.av.z;
   hv[15] = h.au.x; hv[16] = h.au.y; hv[17] = h.au.z;
   if constexpr (HS > 18) {
@@ -308,14 +316,11 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     T yr[19];
 #pragma unroll
     for (int r = 0; r < 19; ++r) yr[r] = Xs[iv * MS_YP + r];
-    T hstep = T(1);
+    // forward-difference step of this lane's column (one LDS read at the lane's own component instead of a
+    // 16-way select over the registers, which the compiler also re-derived after the sweep)
+    const T hstep = col > 0 ? S.fd_eps * fmax(fabs(Xs[iv * MS_YP + (R.comp > 0 ? R.comp : 3)]), T(1)) : T(1);
 #pragma unroll
-    for (int r = 3; r < 19; ++r) {
-      if (r == R.comp) {
-        hstep = S.fd_eps * fmax(fabs(yr[r]), T(1));
-        yr[r] += hstep;
-      }
-    }
+    for (int r = 3; r < 19; ++r) yr[r] += r == R.comp ? hstep : T(0);
     RodState<T> y = rows_to_state(yr);
     const bool st = (storing || flush) && col == 0 && !idle;
 
@@ -693,6 +698,7 @@ struct MsPred {
   double lpa[3];
   bool lp_have;    // lpa was fitted on the previous step (so it can be tested on this one)
   bool lp_good;    // ... and predicted this step to better than 1e-3
+  int lp_age;      // steps since lpa was fitted (a good fit is kept for a few steps)
   int avail;       // time levels behind the newest one that carry information
   int next_order;  // extrapolation order of the coming step (MS_ORDER_LP: the linear predictor)
   T kappa;         // contraction constant handed to ms_newton (MsSolveArgs::kappa)
@@ -714,6 +720,7 @@ __device__ __forceinline__ void ms_pred_init(MsPred<T>& Q, int lane, const MsRol
   }
   Q.lpa[0] = Q.lpa[1] = Q.lpa[2] = 1.0;
   Q.lp_have = Q.lp_good = false;
+  Q.lp_age = 0;
   Q.avail = has_prev ? 1 : 0;
   Q.next_order = Q.avail < predictor ? Q.avail : predictor;
   if (Q.next_order >= MS_HLEV) Q.next_order = MS_HLEV - 1;
@@ -729,7 +736,7 @@ __device__ __forceinline__ void ms_pred_save(const MsPred<T>& Q, double* img, in
   u[0 * WAVE + lane] = Q.lpa[0]; u[1 * WAVE + lane] = Q.lpa[1]; u[2 * WAVE + lane] = Q.lpa[2];
   u[3 * WAVE + lane] = (double)Q.kappa;
   u[4 * WAVE + lane] = (double)Q.avail; u[5 * WAVE + lane] = (double)Q.next_order;
-  u[6 * WAVE + lane] = Q.lp_have ? 1.0 : 0.0; u[7 * WAVE + lane] = Q.lp_good ? 1.0 : 0.0;
+  u[6 * WAVE + lane] = (Q.lp_have ? 1.0 : 0.0) + 2.0 * (double)Q.lp_age; u[7 * WAVE + lane] = Q.lp_good ? 1.0 : 0.0;
 }
 template <typename T>
 __device__ __forceinline__ void ms_pred_load(MsPred<T>& Q, const double* img, int lane) {
@@ -743,7 +750,9 @@ __device__ __forceinline__ void ms_pred_load(MsPred<T>& Q, const double* img, in
   // (uniform values: readfirstlane keeps them, and the control flow that depends on them, scalar)
   Q.avail = __builtin_amdgcn_readfirstlane((int)u[4 * WAVE + lane]);
   Q.next_order = __builtin_amdgcn_readfirstlane((int)u[5 * WAVE + lane]);
-  Q.lp_have = __builtin_amdgcn_readfirstlane((int)u[6 * WAVE + lane]) != 0;
+  const int hv = __builtin_amdgcn_readfirstlane((int)u[6 * WAVE + lane]);
+  Q.lp_have = (hv & 1) != 0;
+  Q.lp_age = hv >> 1;
   Q.lp_good = __builtin_amdgcn_readfirstlane((int)u[7 * WAVE + lane]) != 0;
 }
 
@@ -803,27 +812,40 @@ __device__ __forceinline__ void ms_pred_update(MsPred<T>& Q, int order, int stat
       // any fixed polynomial when the motion is fast against the time step: weighted least squares over the
       // MS_P x 19 components for "this step from the previous three", tested on the step after.
       float err_lp = 0.f;
-      double Sn[9];
+      if (Q.lp_have) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
-#pragma unroll
-      for (int q = 0; q < MS_EPL; ++q) {
-        const int e = lane + q * WAVE;
-        if (e < MS_NE) {
-          const double x = (double)Xs[e];
-          const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
-          const double b0 = h0, b1 = h0 - h1, b2 = h0 - 2.0 * h1 + h2;
-          if (Q.lp_have) err_lp = fmaxf(err_lp, update_ratio(x - (Q.lpa[0] * b0 + Q.lpa[1] * b1 + Q.lpa[2] * b2), x));
-          const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
-          const double w0 = b0 * w, w1 = b1 * w, w2 = b2 * w, xw = x * w;
-          Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
-          Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
+        for (int q = 0; q < MS_EPL; ++q) {
+          const int e = lane + q * WAVE;
+          if (e < MS_NE) {
+            const double x = (double)Xs[e];
+            const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+            err_lp = fmaxf(err_lp, update_ratio(x - (Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2)), x));
+          }
         }
       }
       const float em_lp = wave_max_nonneg(err_lp);
       const bool lp_tested = Q.lp_have;
-      Q.lp_have = false;
-      if (predictor >= MS_ORDER_LP && Q.avail >= 2 && status == KR_ST_CONVERGED) {
+      // a fit that just predicted to better than 1e-3 is kept for up to four steps (its test on the following
+      // steps stays out of sample); otherwise refit now
+      const bool keep_fit = lp_tested && em_lp < 1.0e-3f && Q.lp_age < 3 && status == KR_ST_CONVERGED;
+      Q.lp_age = keep_fit ? Q.lp_age + 1 : 0;
+      Q.lp_have = keep_fit;
+      if (!keep_fit && predictor >= MS_ORDER_LP && Q.avail >= 2 && status == KR_ST_CONVERGED) {
+        double Sn[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < MS_EPL; ++q) {
+          const int e = lane + q * WAVE;
+          if (e < MS_NE) {
+            const double x = (double)Xs[e];
+            const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+            const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
+            const double w0 = h0 * w, w1 = (h0 - h1) * w, w2 = (h0 - 2.0 * h1 + h2) * w, xw = x * w;
+            Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
+            Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
+          }
+        }
 #pragma unroll
         for (int k = 0; k < 9; ++k) Sn[k] = wave_sum_f64(Sn[k]);
         // (N + lam diag N) a = r + lam diag(N) 1: ridge towards quadratic extrapolation, relative per column
@@ -1045,7 +1067,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
       if (j < N) {
         T cv[12];
         load_hist_vec<T, 12>(L.c12 + (size_t)j * 12, cv);
-        build_hist_cold<T, HS>(L.cold, A.hc1, A.hc2, cv, regP[q], L.hist + (size_t)j * HS);
+        build_hist_cold<T, HS, DIAG>(L.cold, A.hc1, A.hc2, cv, regP[q], L.hist + (size_t)j * HS);
 #pragma unroll
         for (int c = 0; c < 12; ++c) regP[q][c] = cv[c];
       }
