@@ -43,7 +43,7 @@ def pmc_traffic(B, N, dtype, path, steps):
     return best
 
 
-def cpu_baseline(N, del_t_unused, sample_steps=24):
+def cpu_baseline(N, del_t_unused, sample_steps=96):
     """Times the oracle (NumPy port of cosserat_ode.py + knode.simulate with
     scipy fsolve - the reference's own execution model) on the host: one rod
     per process on every available core, same workload definition."""
