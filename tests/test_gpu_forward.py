@@ -459,3 +459,80 @@ def test_keep_predictor_chunked_calls(torch_cuda, shooting_mode):
         got = run(chunks, keep, flip)
         assert rel_l2(got[T], one[T]) < 1e-7 and rel_l2(got[17], one[17]) < 1e-7
     h.set_option("persistent", 1 if shooting_mode == "persistent" else 0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomized_parity_vs_oracle(torch_cuda, seed):
+    """Seeded sweep over what the fixed fixtures do not vary together: preset, grid size (odd sizes, sizes around
+    the multiple-shooting threshold), batch size, control type and MLP on/off - GPU batch vs the oracle (its tight
+    Newton solver; the oracle itself is pinned to the reference's fsolve runs by tests/test_oracle_golden.py)."""
+    import cosserat_oracle as orc
+    from knode import simulate_batch
+    rng = np.random.default_rng(100 + seed)
+    mod = [None, "noair", "nsw", "short", "damping", "dampstiff", "lengthstiff", "youngs"][seed % 8]
+    N = int(rng.choice([5, 8, 9, 10, 13, 17, 33, 64, 65]))
+    B = int(rng.choice([1, 3, 5, 9]))
+    T = int(rng.choice([1, 2, 7, 14]))
+    kind = ["sine", "step", "random"][seed % 3]
+    r = make_robot(mod, N)
+    use_mlp = seed % 4 == 3
+    mlp = None
+    if use_mlp:
+        mlp = orc.make_mlp([28, 16, 25], "elu", seed=seed)
+        mlp.weights = [w * 0.05 for w in mlp.weights]
+        inject(r, mlp)
+    ctl = np.empty((B, T, 4))
+    for b in range(B):
+        if kind == "sine":
+            ctl[b] = orc.calc_controls("sine", float(rng.uniform(0.4, 2.5)), r.del_t, T)
+        elif kind == "step":
+            ctl[b] = np.array(orc.calc_controls("step", float(rng.uniform(0.5, 2.0)), r.del_t, 40))[-T:]
+        else:
+            ctl[b] = 5.0 + 2.0 * rng.uniform(size=(T, 4))
+    out = simulate_batch(r, ctl)
+    assert np.all(out["status"] == 0), (mod, N, B, T, kind)
+    D = orc.params_for(mod, N).derived()
+    for b in range(B):
+        want = orc.simulate(D, np.vstack([ctl[b], ctl[b][-1:]]), mlp=mlp, solver="newton")
+        got = out["traj"][b]
+        assert rel_l2(got[:, :, :], want[: T + 1, :25]) < 1e-8, (mod, N, B, T, kind, b)
+
+
+def test_edge_shapes(torch_cuda, shooting_mode):
+    """Empty and extreme shapes: B = 0 and T = 0 are no-ops, the shortest rods the discretisation allows
+    (N = 2, 3: one and two segments), and a batch beyond the latency-mode limit (auto mode then takes the
+    8-rods-per-wave kernel) whose rods equal the same rods solved in small batches."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    from knode import simulate_batch
+    dev = "cuda:0"
+    r = make_robot(None, 12)
+    h = r._native()
+    st = h.new_state(4, torch.float64, n_slots=3)
+    h.init_straight(st[0])
+    G = torch.zeros((4, 6), dtype=torch.float64, device=dev)
+    before = st.clone()
+    h.simulate(torch.zeros((4, 0, 4), dtype=torch.float64, device=dev), st, G)          # T = 0
+    h.simulate(torch.zeros((0, 5, 4), dtype=torch.float64, device=dev), st[:, :0], G[:0])  # B = 0
+    torch.cuda.synchronize()
+    assert torch.equal(st, before)
+    for N in (2, 3):
+        rr = make_robot(None, N)
+        ctl = orc.batch_sine_controls(3, 5, rr.del_t, 3)
+        out = simulate_batch(rr, ctl)
+        assert np.all(out["status"] == 0)
+        D = orc.params_for(None, N).derived()
+        want = orc.simulate(D, np.vstack([ctl[1], ctl[1][-1:]]), solver="newton")
+        assert rel_l2(out["traj"][1], want[:6, :25]) < 1e-8
+    if shooting_mode == "single":
+        return
+    # 2500 rods > ms_batch_limit (2048): force nothing, let the library choose
+    rr = make_robot(None, 20)
+    hh = rr._native()
+    hh.set_option("ms_mode", -1)
+    B, T = 2500, 4
+    ctl = orc.batch_sine_controls(B, T, rr.del_t, 11)
+    big = simulate_batch(rr, ctl, tip_only=True)
+    assert hh.get_option("last_sim_path") == 0 and np.all(big["status"] == 0)
+    small = simulate_batch(rr, ctl[:7], tip_only=True)
+    assert rel_l2(big["tip"][:7], small["tip"]) < 1e-7
