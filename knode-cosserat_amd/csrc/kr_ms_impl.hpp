@@ -97,6 +97,15 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   }
   return s;
 }
+// value of lane SRC in every lane
+template <int SRC>
+__device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), SRC)); }
+template <int SRC>
+__device__ __forceinline__ double lane_bcast(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), SRC), hi = __builtin_amdgcn_readlane((int)(b >> 32), SRC);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename T>
 __device__ __forceinline__ void load_pair(const T* src, T& a, T& b) {
   typedef T V2 __attribute__((ext_vector_type(2)));
@@ -146,7 +155,7 @@ __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = fa
   // tile of mlp_mfma.hpp.  The cold table sits in front of XB so the tile cannot clobber it.
   size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);
   if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
-  size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + alg;
+  size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + 40 + alg;  // 40: Ti (6 x 6 inverse)
   if (persist) n += (size_t)N * 12;
   return (n + 3) & ~size_t(3);
 }
@@ -261,6 +270,7 @@ struct MsLds {
   T* XB;    // [2][MS_YP][8]   condensed block X_g = [a_g | M_g], ping-pong between stages
   T* Tm;    // [6][8]          rows [rhs | T] of the 6x6 system for dG
   T* cold;  // [CD_SIZE]       per-step parameters (see ms_cold_fill)
+  T* Ti;    // [6][6]          inverse of the condensed 6x6 matrix of the last full Newton update (chord check)
   T* c12;   // persistent kernel only: [N][12] leading slots (q w v u) of the newest state
 };
 template <typename T, int HS>
@@ -270,7 +280,8 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist) {
   L.Xs = L.hist + (size_t)N * HS;
   // everything accessed with 16-byte vectors sits at a multiple of 4 elements
   L.cold = L.Xs + ((MS_P * MS_YP + 3) & ~3);
-  L.XB = L.cold + ((CD_SIZE + 3) & ~3);
+  L.Ti = L.cold + ((CD_SIZE + 3) & ~3);
+  L.XB = L.Ti + 40;
   L.Tm = L.XB + 2 * MS_YP * 8;
   L.Es = L.Tm + 48;
   L.c12 = persist ? L.Es + ((WAVE * MS_YP + 3) & ~3) : nullptr;
@@ -310,6 +321,15 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
   T dn_prev = T(-1);  // update norm of the previous iteration (contraction estimate)
   const T kappa_in = S.kappa;
   bool below = false;  // an update at or below the tolerance has been seen
+  // kept from the last full Newton update of this solve, for the chord check of a storing sweep:
+  // this lane's column pair of X_1 .. X_{P-1} (registers), inverse of the 6x6 matrix (L.Ti), the
+  // forward-difference columns (Es)
+  T Xreg[MS_P - 1][2];
+#pragma unroll
+  for (int g = 0; g < MS_P - 1; ++g) Xreg[g][0] = Xreg[g][1] = T(0);
+  bool have_fac = false;
+  const int kp = lane & 3;
+  const int r = 3 + (lane >> 2);
 
   while (true) {
     // ---- start state of this lane ------------------------------------------
@@ -416,140 +436,224 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     KR_STAMP_ADD(stamps.sweep, tq);
 #endif
 
-    // ---- hand the end states over ----------------------------------------------------
-    // Es[lane] = end state E of the unperturbed lanes, forward-difference column
-    // (E - E_unperturbed) / step of the others: column c of A_g = dE_g/dY_g sits at Es[l0_g + 1 + c].
-    {
-      T er[19];
-      state_to_rows(y, er);
-      const int l0own = iv == 0 ? 0 : 7 + 17 * (iv - 1);
-      if (col == 0 && !idle) {
-#pragma unroll
-        for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = er[r];
-      }
-      wave_sync();
-      if (col > 0) {
-        const T ih = fast_rcp(hstep);
-        T e0[19];  // all loads first: the compiler cannot tell that they never alias the stores below
-#pragma unroll
-        for (int r = 0; r < 19; ++r) e0[r] = Es[l0own * MS_YP + r];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = (er[r] - e0[r]) * ih;
-      }
-      wave_sync();
-    }
-
+    // ---- Newton update of this sweep ----------------------------------------------------
+    // A storing sweep that follows a small update is first checked with a CHORD update - the residual of
+    // this sweep through the Jacobian factors of the previous one (forward-difference columns still in Es,
+    // X_g pairs in registers, T^-1 in LDS): it differs from the Newton update by a relative O(|d_prev|) <= 1 %
+    // and costs a third of the full condensation.  If it is below half the tolerance the sweep is accepted;
+    // otherwise the full update below is computed as usual.
 #ifdef KR_MS_STAMPS
     unsigned long long ta = tq;
-    KR_STAMP_ADD(stamps.a1, ta);
 #endif
-    // ---- condensation -------------------------------------------------------------------
-    // dY_1 = c_0 + A_0 dG,  dY_{g+1} = c_g + A_g dY_g  with c_g = E_g - Y_{g+1}; written as
-    // dY_g = X_g [1; dG], X_g = [a_g | M_g] (19 x 7).  The p rows never feed back (no equation reads
-    // p), so the chain runs on rows 3..18 only: lane -> (row r, column pair kp) of X_g, 16 x 4 = 64
-    // lanes, 2 x 16 fused multiply-adds per stage, X_g handed on through a ping-pong LDS tile.
-    const int kp = lane & 3;
-    const int r = 3 + (lane >> 2);
-    T Xreg[MS_P - 1][2];  // this lane's pair of X_1 .. X_{P-1}
-    {
-      const T c0 = Es[0 * MS_YP + r] - Xs[1 * MS_YP + r];
-      const T da = Es[(2 * kp) * MS_YP + r];      // lanes 1..6 hold the columns of A_0 (lane 0: E_0, unused)
-      const T db = Es[(2 * kp + 1) * MS_YP + r];  // (lane 7 is E_1: masked below)
-      Xreg[0][0] = kp == 0 ? c0 : da;
-      Xreg[0][1] = kp == 3 ? T(0) : db;
-      store_pair(XB + r * 8 + 2 * kp, Xreg[0][0], Xreg[0][1]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int g = 1; g < MS_P; ++g) {
-      const T* xcur = XB + ((g - 1) & 1) * (MS_YP * 8);
-      T* xnext = XB + (g & 1) * (MS_YP * 8);
-      const int l0 = 7 + 17 * (g - 1);  // unperturbed lane of interval g
-      const T e0 = Es[l0 * MS_YP + r];
-      T n0 = T(0), n1 = T(0), n2 = T(0), n3 = T(0);
-      if (g < MS_P - 1) {
-        const T cg = e0 - Xs[(g + 1) * MS_YP + r];
-        n0 = kp == 0 ? cg : T(0);
-      }
+    bool chord = storing && have_fac && dn_prev > T(0) && dn_prev <= T(1e-2);
+    T d[6];
+    T updY[MS_P - 1];
+    T* dYb = XB;  // [g][19] scratch for dY_1 .. dY_{P-2} (p rows below)
+    float dnf;
+    bool finite;
+    T updP, updG, xsP, xsG, xsY[MS_P - 1];
+    const bool plane = lane < 3 * (MS_P - 1);
+    const int pi = plane ? lane / 3 : 0;     // term i = 0 .. P-2
+    const int prow = plane ? lane - 3 * pi : 0;
+    const bool glane = lane >= WAVE - 6;  // six otherwise idle lanes own the base wrench
+    while (true) {
+    if (chord) {
+      T* ach = XB;             // a_g, g = 1 .. P-1: [g][19]
+      T* rt = XB + 4 * MS_YP;  // tip right-hand side [6]
+      dYb = XB + MS_YP * 8;
       {
-        // issue all 32 LDS reads of the stage back to back, then the arithmetic (left alone, the
-        // scheduler waits for every read before it issues the next one)
-        T av[16], xa[16], xb[16];
+        T er[19];
+        state_to_rows(y, er);
+        if (col == 0 && !idle) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          av[c] = Es[(l0 + 1 + c) * MS_YP + r];
-          load_pair(xcur + (3 + c) * 8 + 2 * kp, xa[c], xb[c]);
+          for (int q = 0; q < 19; ++q) Es[lane * MS_YP + q] = er[q];
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 16; c += 2) {
-          n0 = fma(av[c], xa[c], n0);
-          n1 = fma(av[c], xb[c], n1);
-          n2 = fma(av[c + 1], xa[c + 1], n2);
-          n3 = fma(av[c + 1], xb[c + 1], n3);
-        }
-        n0 += n2;
-        n1 += n3;
-      }
-      if (g < MS_P - 1) {
-        Xreg[g][0] = n0;
-        Xreg[g][1] = n1;
-        store_pair(xnext + r * 8 + 2 * kp, n0, n1);
-      } else if (r >= 7 && r < 13) {
-        // tip rows: [n;m](E_{P-1} + A_{P-1} dY_{P-1}) = [F_tip; M_tip]  ->  row [rhs | T] of T dG = rhs
-        if (kp == 0) n0 = L.cold[CD_FTIP + (r - 7)] - e0 - n0;  // F_tip (3) and M_tip (3) are adjacent
-        store_pair(Tm + (r - 7) * 8 + 2 * kp, n0, n1);
       }
       wave_sync();
-    }
-
-#ifdef KR_MS_STAMPS
-    KR_STAMP_ADD(stamps.a2, ta);
-#endif
-    // ---- 6x6 solve, redundantly in every lane (registers only) -------------------------
-    T d[6];
-    {
-      T a6[6][7];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        T row[8];
-        load_hist_vec<T, 8>(Tm + i * 8, row);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a6[i][k] = row[1 + k];
-        a6[i][6] = row[0];
-      }
-      solve6(a6, d);
-    }
-
-#ifdef KR_MS_STAMPS
-    KR_STAMP_ADD(stamps.a3, ta);
-#endif
-    // ---- updates and convergence --------------------------------------------------------
-    // rows 3..18 of dY_g: every lane of a quad ends up with the full dot product X_g[r] . [1; dG]
-    T updY[MS_P - 1];
-    {
-      const T dd0 = kp == 0 ? T(1) : kp == 1 ? d[1] : kp == 2 ? d[3] : d[5];
-      const T dd1 = kp == 0 ? d[0] : kp == 1 ? d[2] : kp == 2 ? d[4] : T(0);
+      T areg[MS_P - 1];
+      areg[0] = Es[0 * MS_YP + r] - Xs[1 * MS_YP + r];  // a_1 = c_0
+      if (kp == 0) ach[1 * MS_YP + r] = areg[0];
+      wave_sync();
 #pragma unroll
       for (int g = 1; g < MS_P; ++g) {
-        T s = fma(Xreg[g - 1][1], dd1, Xreg[g - 1][0] * dd0);
-        s += quad_xor<0xB1>(s);  // lanes ^1
-        s += quad_xor<0x4E>(s);  // lanes ^2
-        updY[g - 1] = s;
+        const int l0 = 7 + 17 * (g - 1);
+        T av[4], xv[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          av[cc] = Es[(l0 + 1 + 4 * kp + cc) * MS_YP + r];
+          xv[cc] = ach[g * MS_YP + 3 + 4 * kp + cc];
+        }
+        const T e0 = Es[l0 * MS_YP + r];
+        const T ynext = g < MS_P - 1 ? Xs[(g + 1) * MS_YP + r] : T(0);
+        T part = fma(av[0], xv[0], av[1] * xv[1]) + fma(av[2], xv[2], av[3] * xv[3]);
+        part += quad_xor<0xB1>(part);
+        part += quad_xor<0x4E>(part);
+        if (g < MS_P - 1) {
+          areg[g] = e0 - ynext + part;
+          if (kp == 0) ach[(g + 1) * MS_YP + r] = areg[g];
+        } else if (kp == 0 && r >= 7 && r < 13) {
+          rt[r - 7] = L.cold[CD_FTIP + (r - 7)] - e0 - part;
+        }
+        wave_sync();
+      }
+      {
+        T rtv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) rtv[j] = rt[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          T acc = T(0);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc = fma(L.Ti[i * 6 + j], rtv[j], acc);
+          d[i] = acc;
+        }
+      }
+      {
+        const T dd0 = kp == 0 ? T(0) : kp == 1 ? d[1] : kp == 2 ? d[3] : d[5];  // (the a column is the new one)
+        const T dd1 = kp == 0 ? d[0] : kp == 1 ? d[2] : kp == 2 ? d[4] : T(0);
+#pragma unroll
+        for (int g = 1; g < MS_P; ++g) {
+          T sx = fma(Xreg[g - 1][1], dd1, Xreg[g - 1][0] * dd0);
+          sx += quad_xor<0xB1>(sx);
+          sx += quad_xor<0x4E>(sx);
+          updY[g - 1] = areg[g - 1] + sx;
+        }
+      }
+    } else {
+      dYb = XB;
+      // ---- hand the end states over ----------------------------------------------------
+      // Es[lane] = end state E of the unperturbed lanes, forward-difference column
+      // (E - E_unperturbed) / step of the others: column c of A_g = dE_g/dY_g sits at Es[l0_g + 1 + c].
+      {
+        T er[19];
+        state_to_rows(y, er);
+        const int l0own = iv == 0 ? 0 : 7 + 17 * (iv - 1);
+        if (col == 0 && !idle) {
+  #pragma unroll
+          for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = er[r];
+        }
+        wave_sync();
+        if (col > 0) {
+          const T ih = fast_rcp(hstep);
+          T e0[19];  // all loads first: the compiler cannot tell that they never alias the stores below
+  #pragma unroll
+          for (int r = 0; r < 19; ++r) e0[r] = Es[l0own * MS_YP + r];
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = (er[r] - e0[r]) * ih;
+        }
+        wave_sync();
+      }
+
+  #ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(stamps.a1, ta);
+  #endif
+      // ---- condensation -------------------------------------------------------------------
+      // dY_1 = c_0 + A_0 dG,  dY_{g+1} = c_g + A_g dY_g  with c_g = E_g - Y_{g+1}; written as
+      // dY_g = X_g [1; dG], X_g = [a_g | M_g] (19 x 7).  The p rows never feed back (no equation reads
+      // p), so the chain runs on rows 3..18 only: lane -> (row r, column pair kp) of X_g, 16 x 4 = 64
+      // lanes, 2 x 16 fused multiply-adds per stage, X_g handed on through a ping-pong LDS tile.
+      {
+        const T c0 = Es[0 * MS_YP + r] - Xs[1 * MS_YP + r];
+        const T da = Es[(2 * kp) * MS_YP + r];      // lanes 1..6 hold the columns of A_0 (lane 0: E_0, unused)
+        const T db = Es[(2 * kp + 1) * MS_YP + r];  // (lane 7 is E_1: masked below)
+        Xreg[0][0] = kp == 0 ? c0 : da;
+        Xreg[0][1] = kp == 3 ? T(0) : db;
+        store_pair(XB + r * 8 + 2 * kp, Xreg[0][0], Xreg[0][1]);
+      }
+      wave_sync();
+  #pragma unroll
+      for (int g = 1; g < MS_P; ++g) {
+        const T* xcur = XB + ((g - 1) & 1) * (MS_YP * 8);
+        T* xnext = XB + (g & 1) * (MS_YP * 8);
+        const int l0 = 7 + 17 * (g - 1);  // unperturbed lane of interval g
+        const T e0 = Es[l0 * MS_YP + r];
+        T n0 = T(0), n1 = T(0), n2 = T(0), n3 = T(0);
+        if (g < MS_P - 1) {
+          const T cg = e0 - Xs[(g + 1) * MS_YP + r];
+          n0 = kp == 0 ? cg : T(0);
+        }
+        {
+          // issue all 32 LDS reads of the stage back to back, then the arithmetic (left alone, the
+          // scheduler waits for every read before it issues the next one)
+          T av[16], xa[16], xb[16];
+  #pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            av[c] = Es[(l0 + 1 + c) * MS_YP + r];
+            load_pair(xcur + (3 + c) * 8 + 2 * kp, xa[c], xb[c]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int c = 0; c < 16; c += 2) {
+            n0 = fma(av[c], xa[c], n0);
+            n1 = fma(av[c], xb[c], n1);
+            n2 = fma(av[c + 1], xa[c + 1], n2);
+            n3 = fma(av[c + 1], xb[c + 1], n3);
+          }
+          n0 += n2;
+          n1 += n3;
+        }
+        if (g < MS_P - 1) {
+          Xreg[g][0] = n0;
+          Xreg[g][1] = n1;
+          store_pair(xnext + r * 8 + 2 * kp, n0, n1);
+        } else if (r >= 7 && r < 13) {
+          // tip rows: [n;m](E_{P-1} + A_{P-1} dY_{P-1}) = [F_tip; M_tip]  ->  row [rhs | T] of T dG = rhs
+          if (kp == 0) n0 = L.cold[CD_FTIP + (r - 7)] - e0 - n0;  // F_tip (3) and M_tip (3) are adjacent
+          store_pair(Tm + (r - 7) * 8 + 2 * kp, n0, n1);
+        }
+        wave_sync();
+      }
+
+  #ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(stamps.a2, ta);
+  #endif
+      // ---- 6x6 solve, redundantly in every lane (registers only) -------------------------
+      {
+        T a6[6][7];
+  #pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          T row[8];
+          load_hist_vec<T, 8>(Tm + i * 8, row);
+  #pragma unroll
+          for (int k = 0; k < 6; ++k) a6[i][k] = row[1 + k];
+          a6[i][6] = lane < 6 ? (lane == i ? T(1) : T(0)) : row[0];  // lanes 0..5: unit vectors -> columns of T^-1
+        }
+        T x6[6];
+        solve6(a6, x6);
+        if (lane < 6) {
+  #pragma unroll
+          for (int i = 0; i < 6; ++i) L.Ti[i * 6 + lane] = x6[i];
+        }
+  #pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = lane_bcast<6>(x6[i]);
+        have_fac = true;
+      }
+
+  #ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(stamps.a3, ta);
+  #endif
+      // ---- updates and convergence --------------------------------------------------------
+      // rows 3..18 of dY_g: every lane of a quad ends up with the full dot product X_g[r] . [1; dG]
+      {
+        const T dd0 = kp == 0 ? T(1) : kp == 1 ? d[1] : kp == 2 ? d[3] : d[5];
+        const T dd1 = kp == 0 ? d[0] : kp == 1 ? d[2] : kp == 2 ? d[4] : T(0);
+  #pragma unroll
+        for (int g = 1; g < MS_P; ++g) {
+          T s = fma(Xreg[g - 1][1], dd1, Xreg[g - 1][0] * dd0);
+          s += quad_xor<0xB1>(s);  // lanes ^1
+          s += quad_xor<0x4E>(s);  // lanes ^2
+          updY[g - 1] = s;
+        }
       }
     }
     // the p rows: dY_{g}[p] = sum_{i<g} (c_i[p] + A_i[p,:] dY_i[3:]), one term per lane (i, row)
-    T* dYb = XB;  // the chain is done with its tiles: [g][19] scratch for dY_1 .. dY_{P-2}
     T* sp = Tm;   // [P-1][3] partial sums (the solve has consumed Tm)
     if (kp == 0) {
 #pragma unroll
       for (int g = 1; g < MS_P - 1; ++g) dYb[g * MS_YP + r] = updY[g - 1];
     }
     wave_sync();
-    const bool plane = lane < 3 * (MS_P - 1);
-    const int pi = plane ? lane / 3 : 0;     // term i = 0 .. P-2
-    const int prow = plane ? lane - 3 * pi : 0;
     if (plane) {
       const int l0 = pi == 0 ? 0 : 7 + 17 * (pi - 1);
       T s = Es[l0 * MS_YP + prow] - Xs[(pi + 1) * MS_YP + prow];
@@ -576,9 +680,8 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
 
     // scaled update norm over every unknown (base wrench and interior states).  The norm only steers the
     // iteration (stop test, contraction estimate), so it is formed in fp32 with the hardware reciprocal.
-    float dnf = 0.f;
-    T updP = T(0), updG = T(0), xsP = T(0), xsG = T(0), xsY[MS_P - 1];
-    const bool glane = lane >= WAVE - 6;  // six otherwise idle lanes own the base wrench
+    dnf = 0.f;
+    updP = T(0); updG = T(0); xsP = T(0); xsG = T(0);
     if (plane) {  // this lane owns Y_{pi+1}[prow]
       xsP = Xs[(pi + 1) * MS_YP + prow];
 #pragma unroll
@@ -603,7 +706,13 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       }
     }
     dnf = wave_max_nonneg(dnf);  // +inf if any update is not finite
-    const bool finite = dnf <= 3.0e38f;
+    finite = dnf <= 3.0e38f;
+    if (chord && !(finite && (T)dnf <= T(0.5) * S.tol)) {
+      chord = false;  // not conclusive: compute the Newton update proper
+      continue;
+    }
+    break;
+    }
     const T dn = (T)dnf;
 
     if (finite && !below && dn <= S.tol) {
