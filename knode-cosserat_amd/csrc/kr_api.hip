@@ -222,6 +222,7 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
     a.pred = pred; a.pred_reset = t == 0 && !resume; a.pred_has_prev = prev_init != nullptr; a.pred_limit = h->predictor;
     if (tip) { a.tip = (T*)tip + t * 3; a.tip_stride = T_steps * 3; }
     if (status) { a.status = status + t; a.st_stride = T_steps; }
+    if (h->dbg) { a.iters = static_cast<int32_t*>(h->dbg) + t; a.st_stride = T_steps; }  // diagnostics: sweeps per rod and step, [B][T] int32
     int rc = launch_step<T>(h, scheme, use_nn, a, s);
     if (rc) return rc;
   }

@@ -155,6 +155,7 @@ __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = fa
   // tile of mlp_mfma.hpp.  The cold table sits in front of XB so the tile cannot clobber it.
   size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);
   if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
+  alg = (alg + 3) & ~size_t(3);
   size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + 40 + alg;  // 40: Ti (6 x 6 inverse)
   if (persist) n += (size_t)N * 12;
   return (n + 3) & ~size_t(3);
@@ -274,7 +275,7 @@ struct MsLds {
   T* c12;   // persistent kernel only: [N][12] leading slots (q w v u) of the newest state
 };
 template <typename T, int HS>
-__device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist) {
+__device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist, bool nn = false) {
   MsLds<T> L;
   L.hist = smem;
   L.Xs = L.hist + (size_t)N * HS;
@@ -284,7 +285,9 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist) {
   L.XB = L.Ti + 40;
   L.Tm = L.XB + 2 * MS_YP * 8;
   L.Es = L.Tm + 48;
-  L.c12 = persist ? L.Es + ((WAVE * MS_YP + 3) & ~3) : nullptr;
+  size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);  // as in ms_lds_elems
+  if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
+  L.c12 = persist ? L.XB + ((alg + 3) & ~size_t(3)) : nullptr;
   return L;
 }
 
@@ -1108,8 +1111,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
 // ---------------------------------------------------------------------------
 constexpr int MS_NPL = 2;  // grid points per lane held in registers by the persistent kernel (N <= 128)
 
-template <typename T, bool DIAG, int SCHEME, int HS>
-__global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A) {
+template <typename T, bool DIAG, int SCHEME, int HS, bool NN>
+__global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A, const MlpDev<T> M) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = Pc.N;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1117,7 +1120,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   const int64_t rod = (int64_t)blockIdx.x * MS_WPB + wv;
   if (rod >= A.B) return;  // whole wavefront; there is no workgroup barrier in this kernel
   const size_t rod_elems = (size_t)N * KR_SLOTS;
-  const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, true), N, true);
+  const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, true, NN), N, true, NN);
   const MsRole R = ms_role(lane, N);
   ms_cold_fill<T>(Pc, L.cold, lane);
   wave_sync();
@@ -1183,6 +1186,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     }
     SweepCtx<T, HS> C;
     ms_ctx_init<T, HS>(L.cold, L.hist, tens, C);
+    if constexpr (NN) {  // exchange tile of the matrix-core MLP, on top of the condensation buffers
+      C.tile = L.XB;
+      C.lane = lane;
+    }
     if (t + 1 < A.T_steps) {  // next step's tensions: issued now, consumed after this step's solve
 #pragma unroll
       for (int k = 0; k < 4; ++k) tens[k] = ctl[(t + 1) * 4 + k];
@@ -1201,7 +1208,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
 #ifdef KR_MS_STAMPS
       KR_STAMP_ADD(stamps.prep, tp);
 #endif
-      status = ms_newton<T, DIAG, SCHEME, HS, true, false>(Pc, MlpDev<T>{}, L, R, lane, C, S, it, stamps);
+      status = ms_newton<T, DIAG, SCHEME, HS, true, NN>(Pc, M, L, R, lane, C, S, it, stamps);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the extrapolated start did not converge: redo the step from the reference's warm start
 #ifdef KR_MS_STAMPS
@@ -1298,17 +1305,17 @@ static int launch_ms(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a,
   h->last_sim_path = 1;
   return use_nn ? launch_ms_nn<T, true>(h, scheme, a, s) : launch_ms_nn<T, false>(h, scheme, a, s);
 }
-template <typename T, bool DIAG, int SCHEME>
-static int launch_ms_sim_inst(const RodConst<T>& P, const SimArgs<T>& a, hipStream_t s) {
-  auto kern = ms_sim_kernel<T, DIAG, SCHEME, hs_phys<T>()>;
-  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, true);
+template <typename T, bool DIAG, int SCHEME, bool NN>
+static int launch_ms_sim_inst(const RodConst<T>& P, const MlpDev<T>& M, const SimArgs<T>& a, hipStream_t s) {
+  auto kern = ms_sim_kernel<T, DIAG, SCHEME, hs_phys<T>(), NN>;
+  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, true, NN);
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
     configured = smem;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a, M);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }
@@ -1317,14 +1324,24 @@ static int launch_ms_sim_inst(const RodConst<T>& P, const SimArgs<T>& a, hipStre
 template <typename T>
 int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>& a, hipStream_t s) {
   const RodConst<T>& P = consts<T>(h);
-  if (use_nn || h->ms_mode == 0 || h->persistent == 0) return 1;
+  if (h->ms_mode == 0 || h->persistent == 0) return 1;
+  const MlpDev<T>& M = mlpdev<T>(h);
+  if (use_nn) {
+    // MLP inside the sweeps: the matrix-core evaluator, Euler sweeps and diagonal material matrices only (one
+    // more instantiation of the largest kernel per arithmetic type; everything else takes one launch per step)
+    if (M.n_layers <= 0 || !M.mfma_ok || h->params.nn_input_history || scheme != KR_EULER || !P.diag) return 1;
+    if (P.N - 1 < 2 * MS_P || P.N > MS_NPL * WAVE) return 1;
+    if (ms_lds_bytes<T, hs_phys<T>()>(P.N, true, true) > (size_t)h->lds_limit) return 1;
+    if (h->ms_mode != 1 && a.B > (int64_t)h->ms_batch_limit) return 1;
+    return launch_ms_sim_inst<T, true, KR_EULER, true>(P, M, a, s);
+  }
   if (P.N - 1 < 2 * MS_P || P.N > MS_NPL * WAVE) return 1;
   if (ms_lds_bytes<T, hs_phys<T>()>(P.N, true) > (size_t)h->lds_limit) return 1;
   if (h->ms_mode != 1 && a.B > (int64_t)h->ms_batch_limit) return 1;
   if (scheme == KR_EULER)
-    return P.diag ? launch_ms_sim_inst<T, true, KR_EULER>(P, a, s) : launch_ms_sim_inst<T, false, KR_EULER>(P, a, s);
+    return P.diag ? launch_ms_sim_inst<T, true, KR_EULER, false>(P, M, a, s) : launch_ms_sim_inst<T, false, KR_EULER, false>(P, M, a, s);
   if (scheme == KR_RK4)
-    return P.diag ? launch_ms_sim_inst<T, true, KR_RK4>(P, a, s) : launch_ms_sim_inst<T, false, KR_RK4>(P, a, s);
+    return P.diag ? launch_ms_sim_inst<T, true, KR_RK4, false>(P, M, a, s) : launch_ms_sim_inst<T, false, KR_RK4, false>(P, M, a, s);
   set_error("unknown scheme");
   return KR_E_ARG;
 }

@@ -47,7 +47,8 @@ struct MfmaOp<float> {
 constexpr int MM_IN = 28;       // MLP input width served by this path
 constexpr int MM_KS1 = MM_IN / 4;  // k-steps of the first layer
 constexpr int MM_OUT_T = 2;     // output tiles (25 -> 32)
-constexpr int MM_TILE_LD = 32;  // row length of the LDS exchange tile [64][32]
+constexpr int MM_TILE_LD = 29;  // row pitch of the LDS exchange tile [64][28 in / 25 out]: odd, so that the per-lane rows
+                                // spread over all banks, and small enough for the persistent kernel's LDS budget
 constexpr int MM_SH = 2;        // sample tiles processed together (2 x 16 samples): bounds the register footprint
 
 // what the evaluator needs of MlpDev, passed in scalar registers
@@ -247,7 +248,8 @@ __device__ __attribute__((noinline)) void mlp_mfma_tile(MfmaNet<T> netv, T* tile
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = sizeof(T) == 8 ? (lane >> 4) + 4 * r : 4 * (lane >> 4) + r;
-          tile[(16 * (sh * MM_SH + s) + (lane & 15)) * MM_TILE_LD + 16 * o2 + row] = oacc[o2][s][r];
+          // (units 25..31 of the padded output tiles have no column in the tile)
+          if (16 * o2 + row < 25) tile[(16 * (sh * MM_SH + s) + (lane & 15)) * MM_TILE_LD + 16 * o2 + row] = oacc[o2][s][r];
         }
   }
   mm_wave_sync();
