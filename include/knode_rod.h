@@ -142,8 +142,10 @@ int kr_set_option(kr_handle* h, const char* name, int value);
  * 0 one single-shooting launch per step, 1 one multiple-shooting launch per step, 2 one
  * persistent launch for all steps */
 int kr_get_option(kr_handle* h, const char* name, int* value);
-/* Diagnostic builds only (-DKR_MS_STAMPS): device buffer [B][24] of uint64 that the persistent
- * kernel fills with per-rod cycle counters {total, sweep, algebra, prologue, iterations}. */
+/* Diagnostics (NULL switches them off).  While a buffer is set, kr_simulate_batch with one launch per step
+ * writes the number of Newton sweeps of every rod and step into it as int32 [B][T]; in builds with
+ * -DKR_MS_STAMPS (make dbg) the persistent kernel fills it as uint64 [B][24] with per-rod cycle counters
+ * {total, sweep, algebra, prologue, iterations, ...} instead (tools/ms_stamps.py). */
 int kr_debug_buffer(kr_handle* h, void* dev_ptr);
 /* CosseratRod.compute_intermediate_terms, cosserat_ode.py:58-78 */
 int kr_set_params(kr_handle* h, const kr_params* p);
