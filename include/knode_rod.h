@@ -120,7 +120,8 @@ int kr_destroy(kr_handle* h);
 /* Solver options (integers):
  *   "ms_mode"        -1 auto (default) / 0 off / 1 forced: multiple-shooting form of the time-step
  *                    kernel (one rod per wavefront, 4 sub-intervals) for small batches
- *   "ms_batch_limit" auto mode uses it when B <= limit (default 2048)
+ *   "ms_batch_limit" auto mode uses it when B <= limit (default: no limit - it is the faster kernel at
+ *                    every batch size measured; lower it to send large batches to the single-shooting kernel)
  *   "persistent"     1 (default) / 0: kr_simulate_batch runs all steps in one launch when the
  *                    multiple-shooting kernel applies
  *   "mlp_grad_accumulate" 0 (default) / 1: see kr_adam_step

@@ -1,4 +1,4 @@
-// kr_ms_impl.hpp - multiple-shooting form of the implicit time step ("latency mode").
+// kr_ms_impl.hpp - multiple-shooting form of the implicit time step.
 //
 // Why: at the BASELINE batch (1024 rods) the single-shooting kernel keeps only
 // 128 of the chip's 1024 SIMDs busy, each with a dependent chain of
@@ -1284,7 +1284,7 @@ static bool ms_eligible(kr_handle* h, int use_nn, const StepArgs<T>& a) {
   if (P.N - 1 < 2 * MS_P) return false;                 // too few segments to cut
   if (ms_wpb<T, hs_phys<T>()>(P.N, use_nn != 0, (size_t)h->lds_limit) <= 0) return false;
   if (h->ms_mode == 1) return true;                     // forced
-  return a.B <= (int64_t)h->ms_batch_limit;             // auto: latency mode for small batches
+  return a.B <= (int64_t)h->ms_batch_limit;             // auto (no limit by default: faster at every batch size)
 }
 
 template <typename T, bool NN>

@@ -500,8 +500,8 @@ def test_randomized_parity_vs_oracle(torch_cuda, seed):
 
 def test_edge_shapes(torch_cuda, shooting_mode):
     """Empty and extreme shapes: B = 0 and T = 0 are no-ops, the shortest rods the discretisation allows
-    (N = 2, 3: one and two segments), and a batch beyond the latency-mode limit (auto mode then takes the
-    8-rods-per-wave kernel) whose rods equal the same rods solved in small batches."""
+    (N = 2, 3: one and two segments), and a large batch whose rods equal the same rods solved in small batches,
+    through either kernel (the option ms_batch_limit steers the automatic choice)."""
     torch = torch_cuda
     import cosserat_oracle as orc
     from knode import simulate_batch
@@ -526,13 +526,17 @@ def test_edge_shapes(torch_cuda, shooting_mode):
         assert rel_l2(out["traj"][1], want[:6, :25]) < 1e-8
     if shooting_mode == "single":
         return
-    # 2500 rods > ms_batch_limit (2048): force nothing, let the library choose
+    # auto mode: multiple shooting unless the batch exceeds "ms_batch_limit" (no limit by default)
     rr = make_robot(None, 20)
     hh = rr._native()
     hh.set_option("ms_mode", -1)
     B, T = 2500, 4
     ctl = orc.batch_sine_controls(B, T, rr.del_t, 11)
     big = simulate_batch(rr, ctl, tip_only=True)
-    assert hh.get_option("last_sim_path") == 0 and np.all(big["status"] == 0)
+    assert hh.get_option("last_sim_path") in (1, 2) and np.all(big["status"] == 0)
+    hh.set_option("ms_batch_limit", 2048)
+    big0 = simulate_batch(rr, ctl, tip_only=True)
+    assert hh.get_option("last_sim_path") == 0 and np.all(big0["status"] == 0)
     small = simulate_batch(rr, ctl[:7], tip_only=True)
-    assert rel_l2(big["tip"][:7], small["tip"]) < 1e-7
+    assert hh.get_option("last_sim_path") in (1, 2)
+    assert rel_l2(big["tip"][:7], small["tip"]) < 1e-7 and rel_l2(big0["tip"][:7], small["tip"]) < 1e-7
