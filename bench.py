@@ -255,9 +255,38 @@ def main():
                 errs = [float(_np.linalg.norm(g[b] - tips[b]) / _np.linalg.norm(tips[b])) for b in range(len(tips))]
                 out["tip_rel_l2_vs_oracle"] = max(errs)
             out["cpu_baseline"] = cb
+            try:
+                out["cpu_baseline_c"] = cpu_baseline_c(N, robot.del_t)
+            except Exception as e:  # the C restatement is optional test infrastructure (needs gcc or its prebuilt .so)
+                out["cpu_baseline_c"] = {"error": str(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline_c(N, del_t, rods=256, steps=150):
+    """The scalar C restatement (oracle/cosserat_oracle_c.c, Newton shooting) on all host cores, one rod per call,
+    threads (the C call releases the GIL): what an optimised CPU implementation of the same discrete equations
+    reaches, beside the NumPy port that has the reference's own execution model."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from concurrent.futures import ThreadPoolExecutor
+    import cosserat_oracle as orc
+    import cosserat_oracle_c as oc
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    P = orc.params_for(None, N)
+    ctl = orc.batch_sine_controls(rods, steps, del_t, 1235)
+    oc.simulate(P, ctl[0][:4], traj=False)  # load + build outside the timed region
+    t0 = time.perf_counter()
+    one = oc.simulate(P, ctl[0], traj=False)
+    t_single = time.perf_counter() - t0
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        res = list(ex.map(lambda c: oc.simulate(P, c, traj=False), ctl))
+        t_all = time.perf_counter() - t0
+    return {"value": round(rods * steps / t_all, 1), "unit": "rod-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{rods} rods x {steps} steps of the bench workload (N={N}, fp64), scalar C, Newton shooting to 1e-12, "
+                      f"one rod per thread", "single_core_value": round(steps / t_single, 1),
+            "unconverged": int(sum(r[2] for r in res) + one[2])}
 
 
 def _cpu_ctl(b, steps, del_t):

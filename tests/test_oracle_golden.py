@@ -154,3 +154,31 @@ def test_controls_and_euler():
         orc.calc_controls("ramp", 1.0, 0.05, 3)
     with pytest.raises(Exception):
         orc.setup_params("bogus")
+
+
+# ---------------------------------------------------------------------------
+# the scalar C restatement (oracle/cosserat_oracle_c.c) against the same reference trajectories
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,N,tol", [("sim_cfg1", 20, 1e-10), ("sim_n100", 100, 1e-9), ("sim_n400", 400, 1e-8)])
+def test_c_oracle_tips_vs_reference(name, N, tol):
+    """orc_simulate (Newton to 1e-12) reproduces the tip paths the REFERENCE produced with fsolve."""
+    import cosserat_oracle_c as oc
+    g = load_golden(name)
+    P = orc.params_for(None, N)
+    tip, tr, bad = oc.simulate(P, g["ctl"])
+    assert bad == 0
+    ref = g["tip"]  # entry 0 = initial tip, last solve dropped (knode.py:96-102)
+    got = np.concatenate([tr[0, :3, -1][None], tip])[: len(ref)]
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol
+
+
+@pytest.mark.parametrize("mod", [None, "noair", "nsw", "short", "damping", "dampstiff", "lengthstiff", "youngs"])
+def test_c_oracle_vs_numpy_oracle(mod):
+    """Full states (all 25 rows) of the C and the NumPy restatement agree for every preset."""
+    import cosserat_oracle_c as oc
+    P = orc.params_for(mod, 13)
+    ctl = np.array(orc.calc_controls("sine", 0.7, P.del_t, 12))
+    want = orc.simulate(P.derived(), np.vstack([ctl, ctl[-1:]]), solver="newton")
+    tip, tr, bad = oc.simulate(P, ctl)
+    assert bad == 0
+    assert np.linalg.norm(tr - want[:13, :25]) / np.linalg.norm(want[:13, :25]) < 1e-10
