@@ -246,9 +246,9 @@ int kr_next_segment_physics(kr_handle* h, int64_t S, int K, const void* Gs, cons
                             const void* tensions, const int32_t* idx, void* x, int in_pad, void* base,
                             int dtype, void* stream);
 
-/* MLP forward over Q rows on the matrix cores (v_mfma_f32_32x32x2_f32: exact
- * fp32, the reference's training precision): out[Q][32] (columns 0..24 valid,
- * 25..31 zero) = MLP(x[Q][in_pad]); keeps pre-activations and activations of
+/* MLP forward over Q rows on the matrix cores (fp32 MFMA: exact fp32, the
+ * reference's training precision): out[Q][32] (columns 0..dims[n_layers]-1 valid -
+ * 25 for the rod's MLP, at most 32 - the rest zero) = MLP(x[Q][in_pad]); keeps pre-activations and activations of
  * the hidden layers in `ws` (kr_mlp_ws_bytes) for the backward pass.  Weights
  * are the caller's device tensors (torch parameters), row-major like nn.Linear:
  * W[k][dims[k+1]][dims[k]], b[k][dims[k+1]]; acts[n_layers-1] must be NONE. */

@@ -240,7 +240,7 @@ class CosseratRodTorch:
                 raise kn.KrError("Linear layers of the residual MLP need a bias")
             params += [l.weight, l.bias]
         out = _MlpFunction.apply(self._native(), x_padded, tuple(dims), tuple(acts), *params)
-        return out[:, :25]
+        return out[:, :dims[-1]]
 
     def forward(self, x):
         """cosserat_ode_torch.py:131-134; accepts [in] or [Q, in]."""

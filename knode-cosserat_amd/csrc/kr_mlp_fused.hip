@@ -16,8 +16,8 @@
 // kernel stores nothing but OUT), so a training step moves X, OUT and dOUT through HBM exactly once:
 // 3 x 128 B per row.  Weights are re-packed into MFMA fragment order on the device at every call
 // (they are torch parameters that change every optimizer step; ~30 KB).
-// Shapes served: in(<=32) -> H1 -> 25 with any H1 (streamed in chunks of 64 units) and
-// in -> H1 -> H2 -> 25 with H1, H2 <= 64; one activation for all hidden layers.  Other networks
+// Shapes served: in(<=32) -> H1 -> out(<=32) with any H1 (streamed in chunks of 64 units) and
+// in -> H1 -> H2 -> out with H1, H2 <= 64; one activation for all hidden layers.  Other networks
 // use the generic GEMM path of kr_train.hip.
 #include <type_traits>
 
@@ -240,6 +240,7 @@ struct FusedArgs {
   int64_t Q;
   int L;                 // 2 or 3 layers
   int in, h1, h2;        // true widths (h2 unused for L == 2)
+  int nout;              // width of the last layer (<= 32; 25 for the rod's MLP)
   int c1;                // hidden chunks of layer 1 (h1 padded to 64*c1)
   const float* x;        // [Q][32]
   const float* dout;     // [Q][32] (backward)
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64) void mlp_fwd_fused_kernel(const FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int u = 16 * o + 4 * (lane >> 4) + r;
-          tx[(16 * s + (lane & 15)) * F_LDX + u] = u < 25 ? oacc[o][s][r] : 0.f;
+          tx[(16 * s + (lane & 15)) * F_LDX + u] = u < A.nout ? oacc[o][s][r] : 0.f;
         }
     fsync();
     const int64_t row = rb * 64 + lane;
@@ -441,25 +442,25 @@ __global__ __launch_bounds__(64) void mlp_bwd_fused_kernel(const FusedArgs A) {
   }
   // ---- one flush per wave ------------------------------------------------------------------------------
   if constexpr (L == 3) {
-    wgrad_flush<2, 4>(aW3, A.dW[2], 25, A.h2, 0, 0, lane);
+    wgrad_flush<2, 4>(aW3, A.dW[2], A.nout, A.h2, 0, 0, lane);
     wgrad_flush<4, 4>(aW2, A.dW[1], A.h2, A.h1, 0, 0, lane);
     wgrad_flush<4, 2>(aW1, A.dW[0], A.h1, A.in, 0, 0, lane);
     bias_flush(pb2, A.db[1], A.h2, 0, lane);
     bias_flush(pb1, A.db[0], A.h1, 0, lane);
-    if (lane < 25) atomicAdd(&A.db[2][lane], pbo);
+    if (lane < A.nout) atomicAdd(&A.db[2][lane], pbo);
   } else {
     const f4(&aWo)[2][4] = reinterpret_cast<const f4(&)[2][4]>(aW2);
-    wgrad_flush<2, 4>(aWo, A.dW[1], 25, A.h1, 0, 64 * chunk, lane);
+    wgrad_flush<2, 4>(aWo, A.dW[1], A.nout, A.h1, 0, 64 * chunk, lane);
     wgrad_flush<4, 2>(aW1, A.dW[0], A.h1, A.in, 64 * chunk, 0, lane);
     bias_flush(pb1, A.db[0], A.h1, 64 * chunk, lane);
-    if (chunk == 0 && lane < 25) atomicAdd(&A.db[1][lane], pbo);
+    if (chunk == 0 && lane < A.nout) atomicAdd(&A.db[1][lane], pbo);
   }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
 bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad) {
   if (n_layers != 2 && n_layers != 3) return false;
-  if (in_pad != 32 || dims[0] > 32 || dims[n_layers] != 25) return false;
+  if (in_pad != 32 || dims[0] > 32 || dims[n_layers] > 32 || dims[n_layers] < 1) return false;
   if (acts[n_layers - 1] != KR_ACT_NONE) return false;
   if (n_layers == 3 && (dims[1] > 64 || dims[2] > 64 || acts[0] != acts[1])) return false;
   return true;
@@ -489,6 +490,7 @@ static int fused_pack(FusedArgs& A, int n_layers, const int32_t* dims, const flo
   A.in = dims[0];
   A.h1 = dims[1];
   A.h2 = n_layers == 3 ? dims[2] : 0;
+  A.nout = dims[n_layers];
   A.c1 = (dims[1] + 63) / 64;
   float* p = ws;
   int prev_tiles = 2;

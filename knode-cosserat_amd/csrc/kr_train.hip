@@ -442,8 +442,8 @@ static int check_mlp_shape(int n_layers, const int32_t* dims) {
       set_error("bad layer width");
       return KR_E_ARG;
     }
-  if (dims[n_layers] != 25) {
-    set_error("the residual MLP must end in 25 outputs (cosserat_ode_torch.py:62)");
+  if (dims[n_layers] > 32) {  // out / dout rows are [32]; the rod's MLP has 25 (cosserat_ode_torch.py:62)
+    set_error("the last layer of the training MLP must have at most 32 outputs");
     return KR_E_ARG;
   }
   return KR_OK;

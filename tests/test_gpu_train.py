@@ -198,6 +198,8 @@ def test_no_nn_self_consistency(torch_cuda):
     ([28, 64, 64, 25], ["elu", "elu"], 1000),
     ([53, 64, 25], ["tanh"], 257),
     ([28, 48, 80, 25], ["softplus", "relu"], 3001),
+    ([18, 64, 64, 6], ["elu", "elu"], 4099),   # the literal network of BASELINE.json configs[2] (fused kernels)
+    ([18, 96, 6], ["tanh"], 300),
 ])
 def test_mlp_forward_backward_vs_torch(torch_cuda, sizes, acts, Q):
     """MFMA GEMM chain against torch (fp64 reference of the same fp32 weights)."""
@@ -214,7 +216,7 @@ def test_mlp_forward_backward_vs_torch(torch_cuda, sizes, acts, Q):
             mods.append(amap[acts[k]]())
     rob.nn_models = nn.ModuleList(mods).to(DEV)
     x = torch.randn(Q, sizes[0], device=DEV)
-    gout = torch.randn(Q, 25, device=DEV)
+    gout = torch.randn(Q, sizes[-1], device=DEV)
     out = rob.forward(x)
     (out * gout).sum().backward()
     got = [p.grad.clone() for p in rob.nn_models.parameters()]

@@ -79,6 +79,32 @@ def train_epoch(M, T, N, kp, layers):
     return best, tr.Q, 6 * tr.Q * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
 t, Q, fl = train_epoch(1024, 64, 100, [22, 67, 99], [64, 64])
 print(f"      training epoch (fwd + loss + bwd + Adam + clamp), Q={Q} rows: {t*1e6:7.1f} us -> {1024*63/t/1e6:6.1f} M trajectory-steps/s, {fl/t/1e12:5.1f} TFLOP/s fp32 useful")
+# the literal network of BASELINE.json configs[2], 18 -> 64 -> 64 -> 6, as a bare forward + backward over the same Q rows
+import ctypes as C
+import krod_native as kn
+hh = robot(100)._native()
+dims = [18, 64, 64, 6]; Qr = 193536
+gen = torch.Generator(device=dev); gen.manual_seed(0)
+Ws = [torch.randn(dims[k + 1], dims[k], device=dev, generator=gen) * 0.1 for k in range(3)]
+bs = [torch.randn(dims[k + 1], device=dev, generator=gen) * 0.1 for k in range(3)]
+dWs = [torch.zeros_like(w) for w in Ws]; dbs = [torch.zeros_like(b) for b in bs]
+xq = torch.zeros((Qr, 32), device=dev); xq[:, :18] = torch.randn(Qr, 18, device=dev, generator=gen)
+outq = torch.zeros((Qr, 32), device=dev); doutq = torch.zeros((Qr, 32), device=dev); doutq[:, :6] = 1.0
+dims_c = (C.c_int32 * 4)(*dims); acts_c = (C.c_int32 * 3)(4, 4, 0)
+wsq = torch.empty(max(hh.lib.kr_mlp_ws_bytes(3, dims_c, Qr), 16), dtype=torch.uint8, device=dev)
+Wp = (C.c_void_p * 3)(*[w.data_ptr() for w in Ws]); bp = (C.c_void_p * 3)(*[b.data_ptr() for b in bs])
+dWp = (C.c_void_p * 3)(*[w.data_ptr() for w in dWs]); dbp = (C.c_void_p * 3)(*[b.data_ptr() for b in dbs])
+def fb():
+    kn.check(hh.lib.kr_mlp_forward(hh._h, Qr, 3, dims_c, acts_c, Wp, bp, kn._ptr(xq), 32, kn._ptr(outq), kn._ptr(wsq), kn._stream()))
+    kn.check(hh.lib.kr_mlp_backward(hh._h, Qr, 3, dims_c, acts_c, Wp, kn._ptr(xq), 32, kn._ptr(doutq), kn._ptr(wsq), dWp, dbp, kn._stream()))
+for _ in range(3): fb()
+torch.cuda.synchronize(); best = 1e9
+for _ in range(5):
+    t0 = time.perf_counter()
+    for _ in range(5): fb()
+    torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 5)
+fl = 6 * Qr * (18 * 64 + 64 * 64 + 64 * 6)
+print(f"      bare MLP 18->64->64->6 (BASELINE-literal), forward + backward over Q={Qr} rows: {best*1e6:7.1f} us, {fl/best/1e12:5.1f} TFLOP/s fp32 useful")
 rr = robot(100); mlp = orc.make_mlp([28, 64, 64, 25], "elu", seed=7)
 model, params = [], []
 for W, b, a in zip(mlp.weights, mlp.biases, mlp.acts):
