@@ -376,3 +376,25 @@ def test_evaluate_closed_loop_rollout(torch_cuda):
     assert np.array_equal(again, traj)
     # the reference's own NN-on rollout (weights there in fp64: agreement at the fp32 rounding of the parameters)
     assert rel_l2(traj, g["elu64_traj"][: len(traj), :25]) < 1e-5
+
+
+def test_training_driver_end_to_end(torch_cuda, tmp_path, capsys):
+    """train_knode.py (the physics_train.py-shaped driver): data from the true parameters, a model with the wrong
+    damping plus the MLP, 60 fused epochs - the loss falls, the lines physics_multitrain.py parses are printed, the
+    closed-loop evaluation runs, and the checkpoint is in the reference's layout."""
+    torch = torch_cuda
+    import re
+    import train_knode
+    import krod_checkpoint as kc
+    path = str(tmp_path / "m.pth")
+    loss, dtw = train_knode.main(["sine", "2", "--fast", "--mod", "damping", "--epochs", "60", "--layers", "32",
+                                  "--save", path])
+    out = capsys.readouterr().out
+    assert re.search(r"Epoch (\d+)", out) and re.search(r"Total loss: (.*?), lr (.*?)", out)
+    assert "Validation DTW Distance XYZ" in out
+    assert len(loss) == 60 and loss[-1] < 0.5 * loss[0]
+    assert len(dtw) == 2 and all(np.isfinite(d[0]) for d in dtw)
+    ck = kc.load_checkpoint(path, DEV)
+    assert len(ck["loss"]) == 60 and len(ck["robot"].nn_models) == 3
+    assert ck["robot"].nn_models[0].weight.shape == (32, 28)
+    assert float(ck["robot"].nn_models[0].weight.detach().min()) >= 0.0  # the clamp of physics_train.py:299-304
