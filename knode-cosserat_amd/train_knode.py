@@ -73,11 +73,17 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # KR_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the data-parallel path on a 1-GPU box)
+    backend = os.environ.get("KR_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
     say = print if rank == 0 else (lambda *a, **k: None)
 
     data_short = f'physics_{"-".join(control_type)}_{"-".join(map(str, control_arg))}'.replace(".", "_")
@@ -86,9 +92,9 @@ def main(argv=None):
 
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
-    robot_reference = CosseratRod(use_fsolve=True, device=local_rank)   # generates the data (true parameters)
+    robot_reference = CosseratRod(use_fsolve=True, device=dev_index)   # generates the data (true parameters)
     setup_robot(robot_reference)
-    robot_eval = CosseratRod(use_fsolve=True, device=local_rank)        # imperfect model + MLP, for evaluation
+    robot_eval = CosseratRod(use_fsolve=True, device=dev_index)        # imperfect model + MLP, for evaluation
     setup_robot(robot_eval, args.mod)
     robot = CosseratRodTorch(device, args.layers)                       # imperfect model + trainable MLP
     setup_robot(robot, args.mod)
