@@ -138,6 +138,9 @@ def main():
     # W is rounded up to a multiple of 3 so that the timed call starts at ring slot 0 again, with the
     # state before it in slot 2 (handed over as state_prev_init: the run continues exactly).
     W = (W + 2) // 3 * 3
+    # the start-value predictor needs about 20 steps of history to settle: never fewer
+    # warm-up steps than that, whatever was asked for; the JSON line reports the number actually done
+    W = max(W, 30)
     i = np.arange(1, W + K + 1)[None, :, None]
     ctl = 6.0 + np.sin(2 * np.pi * i * robot.del_t / Pd[:, None, None] + phi[:, None, None] + k * (np.pi / 2))
     ctl_w = torch.as_tensor(ctl[:, :W], device=dev).to(tdt).contiguous()
