@@ -12,6 +12,12 @@ as ONE persistent launch in which every wavefront keeps its rod, DESIGN.md secti
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nodes-per-rod N] [--dtype f64|f32]
 
+The batch is ONE trajectory per rod from the straight rod: `settle` + W untimed steps, then the K timed
+ones.  W is what the command line asks for; `settle` (reported separately) tops the untimed part up to 30
+steps, the time the start-value predictor of the solver needs to reach its steady state.  What a cold
+start costs is reported next to it (`cold_start`: T = 64 and T = 200 from the straight rod, no hand-over).
+Rods 0..31 of the timed batch are compared with the CPU oracle over the untimed AND the first timed steps.
+
 N>1: launched by torch.distributed.run, one rank per GPU; rods are sharded
 (weak scaling, no data-path collective); the only collectives are the timing
 barrier and the MAX over ranks of the elapsed time.
@@ -19,63 +25,99 @@ barrier and the MAX over ranks of the elapsed time.
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "knode-cosserat_amd"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP64_VALU_PEAK_TF = 78.6   # public MI355X fp64 vector peak = 1024 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+SETTLE_TOTAL = 30          # untimed steps the predictor needs
+SEED = 1235
 
 
-def pmc_traffic(B, N, dtype, path, steps):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_hbm.json,
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if no profile matches this workload."""
+def rank_controls(B, world, rank, steps, del_t, first_step=1):
+    """Tensions [B, steps, 4] of this rank's rods: rod b of the GLOBAL batch of world x B rods has
+    period P_b ~ U[0.5, 3] s and phase phi_b ~ U[0, 2 pi) from default_rng(1235); rank r owns rods
+    [r B, (r + 1) B).  Step i (1-based from the straight rod) applies 6 + sin(2 pi i dt / P_b + phi_b + k pi / 2)."""
+    import numpy as np
+    rng = np.random.default_rng(SEED)
+    Pd = rng.uniform(0.5, 3.0, size=B * world)[rank * B:(rank + 1) * B]
+    phi = rng.uniform(0.0, 2 * np.pi, size=B * world)[rank * B:(rank + 1) * B]
+    k = np.arange(4)[None, None, :]
+    i = np.arange(first_step, first_step + steps)[None, :, None]
+    return 6.0 + np.sin(2 * np.pi * i * del_t / Pd[:, None, None] + phi[:, None, None] + k * (np.pi / 2))
+
+
+def committed_profile(B, N, dtype, path, kind):
+    """Per-rod-step figures from the newest committed rocprofv3 --pmc summary of this workload
+    (profiles/*pmc_<kind>.json, written by tools/summarise_profiles.py); None if there is none."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{kind}.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") == f"B={B} N={N} {dtype} Euler" and d.get("sim_path", 0) == path and d.get("steps_per_launch", 1) == steps:
-            best = d.get("hbm_bytes_per_launch_corrected")
+        if d.get("workload", f"B={B} N={N} {dtype} Euler") != f"B={B} N={N} {dtype} Euler":
+            continue
+        if kind == "hbm" and d.get("sim_path", 2) != path:
+            continue
+        d["_file"] = os.path.basename(f)
+        best = d
     return best
 
 
-def cpu_baseline(N, del_t_unused, sample_steps=50):
-    """Times the oracle (NumPy port of cosserat_ode.py + knode.simulate with
-    scipy fsolve - the reference's own execution model) on the host: one rod
-    per process on every available core, same workload definition."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(N, del_t, B, sample_steps, rods=None):
+    """Times the oracle (NumPy port of cosserat_ode.py + knode.simulate with scipy fsolve - the reference's own
+    execution model) on the host: one rod per process on every available core, rods 0.. of rank 0's TIMED batch,
+    from the straight rod.  Median of 3 runs.  Returns (record, tips[rods][steps][3])."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import multiprocessing as mp
     cores = min(len(os.sched_getaffinity(0)), 16)
+    rods = rods or 2 * cores  # SURVEY 8d: >= 32 rods x 50 steps on all host cores
+    ctl = rank_controls(B, 1, 0, sample_steps, del_t)[:rods]
     t0 = time.perf_counter()
-    single = _cpu_worker((N, 0, sample_steps))
+    _cpu_worker((N, ctl[0]))
     t_single = time.perf_counter() - t0
-    rods = 2 * cores  # SURVEY 8d: >= 32 rods x 50 steps on all host cores
+    rates, tips = [], None
     with mp.get_context("fork").Pool(cores) as pool:
-        t0 = time.perf_counter()
-        tips = pool.map(_cpu_worker, [(N, b, sample_steps) for b in range(rods)], chunksize=1)
-        t_all = time.perf_counter() - t0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tips = pool.map(_cpu_worker, [(N, ctl[b]) for b in range(rods)], chunksize=1)
+            rates.append(rods * sample_steps / (time.perf_counter() - t0))
     return {
-        "value": round(rods * sample_steps / t_all, 3),
+        "value": round(statistics.median(rates), 3),
         "unit": "rod-steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{rods} rods x {sample_steps} steps of the bench workload (N={N}, fp64, fsolve shooting), "
-                  f"one rod per process, {cores} processes",
+        "sample": f"rods 0..{rods - 1} of the timed batch x {sample_steps} steps from the straight rod (N={N}, fp64, "
+                  f"fsolve shooting), one rod per process, {cores} processes, median of 3 runs",
+        "runs": [round(r, 3) for r in rates],
         "single_core_value": round(sample_steps / t_single, 3),
+        "cpu_model": cpu_model(),
     }, tips
 
 
 def _cpu_worker(args):
-    N, b, steps = args
+    N, ctl = args
     os.environ["OMP_NUM_THREADS"] = "1"
     import numpy as np
     import cosserat_oracle as orc
     D = orc.params_for(None, N).derived()
-    ctl = orc.batch_sine_controls(max(b + 1, 16), steps, D.P.del_t, 1235)[b]
     # the oracle mirrors knode.simulate: T controls -> T solves, last one dropped from the output
     traj = orc.simulate(D, np.vstack([ctl, ctl[-1:]]), solver="fsolve")
     return traj[1:, :3, -1]
@@ -89,12 +131,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="rods per GPU")
     ap.add_argument("--nodes-per-rod", type=int, default=100, help="N, grid points per rod")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg and the cold-start runs")
     args = ap.parse_args()
 
     import numpy as np
     import torch
-    import krod_native as kn
+    import krod_native as kn  # noqa: F401
     from cosserat_ode import CosseratRod
     from knode import setup_robot
 
@@ -114,7 +156,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            dist.init_process_group("nccl", device_id=torch.device(dev))  # before any other GPU call of this process
         else:
             dist.init_process_group(backend)
 
@@ -128,53 +170,64 @@ def main():
     robot.compute_intermediate_terms()
     h = robot._native()
 
-    # synthetic inputs, SURVEY 8d: rod b of the global batch gets its own period and phase
-    rng = np.random.default_rng(1235)
-    Pd = rng.uniform(0.5, 3.0, size=B * world)[rank * B:(rank + 1) * B]
-    phi = rng.uniform(0.0, 2 * np.pi, size=B * world)[rank * B:(rank + 1) * B]
-    k = np.arange(4)[None, None, :]
-
-    # state lives in HBM as a 3-slot ring of packed states; kr_simulate_batch advances it W (+K) steps.
-    # W is rounded up to a multiple of 3 so that the timed call starts at ring slot 0 again, with the
-    # state before it in slot 2 (handed over as state_prev_init: the run continues exactly).
-    W = (W + 2) // 3 * 3
-    # the start-value predictor needs about 20 steps of history to settle: never fewer
-    # warm-up steps than that, whatever was asked for; the JSON line reports the number actually done
-    W = max(W, 30)
-    i = np.arange(1, W + K + 1)[None, :, None]
-    ctl = 6.0 + np.sin(2 * np.pi * i * robot.del_t / Pd[:, None, None] + phi[:, None, None] + k * (np.pi / 2))
-    ctl_w = torch.as_tensor(ctl[:, :W], device=dev).to(tdt).contiguous()
-    ctl_k = torch.as_tensor(ctl[:, W:], device=dev).to(tdt).contiguous()
-    states = h.new_state(B, tdt, n_slots=3)
-    h.init_straight(states[0])
+    settle = max(0, SETTLE_TOTAL - W)
+    pre = settle + W  # untimed steps of the trajectory
+    ctl = rank_controls(B, world, rank, pre + K, robot.del_t)
+    ctl_pre = torch.as_tensor(ctl[:, :pre], device=dev).to(tdt).contiguous() if pre else None
+    ctl_k = torch.as_tensor(ctl[:, pre:], device=dev).to(tdt).contiguous()
     G = torch.zeros((B, 6), dtype=tdt, device=dev)
     status = torch.zeros((B, K), dtype=torch.int32, device=dev)
     tip = torch.empty((B, K, 3), dtype=tdt, device=dev)
+    tip_pre = torch.empty((B, max(pre, 1), 3), dtype=tdt, device=dev)
 
-    # clock ramp, not part of the W warm-up steps: an idle MI355X needs a few hundred ms of load before
-    # its shader clock settles; the same kernel runs on a scratch copy of the problem until then
-    # (ramp and warm-up steps go through the one-launch-per-step form of the same solver, so that the
-    # persistent kernel appears in a rocprofv3 trace exactly once: the timed K steps)
+    def run_cold(T, ramp_only=False):
+        """T steps from the straight rod with no predictor hand-over: (seconds, unconverged rod-steps)."""
+        c = torch.as_tensor(rank_controls(B, world, rank, T, robot.del_t), device=dev).to(tdt).contiguous()
+        st = h.new_state(B, tdt, n_slots=3)
+        g0 = torch.zeros((B, 6), dtype=tdt, device=dev)
+        stat = torch.zeros((B, T), dtype=torch.int32, device=dev)
+        h.init_straight(st[0])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        h.simulate(c, st, g0, ring=True, status=stat)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3, int((stat != 0).sum())
+
+    # clock ramp, not part of the untimed steps: an idle MI355X needs a few hundred ms of load before its shader
+    # clock settles; the same solver runs on scratch copies of the problem until then.  (Ramp and untimed steps go
+    # through the one-launch-per-step form of the same solver, so that the persistent kernel appears in a
+    # rocprofv3 trace of `bench.py --no-cpu` exactly once: the timed K steps.)
+    h.set_option("keep_predictor", 0)
     persistent_default = h.get_option("persistent")
     h.set_option("persistent", 0)
-    scratch = h.new_state(B, tdt, n_slots=3)
-    Gs = torch.zeros((B, 6), dtype=tdt, device=dev)
-    ctl_r = (ctl_w if W else ctl_k[:, :30]).contiguous()
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.5:
-        h.init_straight(scratch[0])
-        Gs.zero_()
-        h.simulate(ctl_r, scratch, Gs, ring=True)
-        torch.cuda.synchronize()
-    del scratch
+        run_cold(30)
+    h.set_option("persistent", persistent_default)
 
-    # the W warm-up steps and the K timed steps are one trajectory advanced by two calls: the second call
-    # resumes the start-value predictor of the first (option "keep_predictor"), so that a short timed region
-    # is as representative of the steady state as a long one
-    h.set_option("keep_predictor", 0)
+    cold = None
+    if not args.no_cpu:
+        cold = {}
+        for T in (64, 200):
+            secs, bad = min(run_cold(T) for _ in range(2))
+            cold[f"T{T}"] = {"value": round(B * T / secs, 1), "ms_per_step": round(secs / T * 1e3, 4), "unconverged": bad}
+
+    # the untimed and the timed steps are one trajectory advanced by two calls: the second call resumes the
+    # start-value predictor of the first (option "keep_predictor")
+    h.set_option("persistent", 0)
     h.set_option("keep_predictor", 1)
-    if W:
-        h.simulate(ctl_w, states, G, ring=True)
+    pre_states = h.new_state(B, tdt, n_slots=pre + 1) if pre else None
+    states = h.new_state(B, tdt, n_slots=3)
+    if pre:
+        h.init_straight(pre_states[0])
+        h.simulate(ctl_pre, pre_states, G, tip=tip_pre)
+        states[0].copy_(pre_states[pre])
+        prev_init = pre_states[pre - 1]
+    else:
+        h.init_straight(states[0])
+        prev_init = None
     h.set_option("persistent", persistent_default)
     torch.cuda.synchronize()
     if world > 1:
@@ -183,7 +236,7 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     ev0.record()
-    h.simulate(ctl_k, states, G, ring=True, tip=tip, status=status, prev_init=states[2] if W else None)
+    h.simulate(ctl_k, states, G, ring=True, tip=tip, status=status, prev_init=prev_init)
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
@@ -193,6 +246,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = ev0.elapsed_time(ev1)  # duration of the K-step region on the launch stream (HIP events)
+    h.set_option("keep_predictor", 0)
 
     n_bad = int((status != 0).sum())
 
@@ -204,9 +258,24 @@ def main():
         # form (history never leaves the CU); (75 N + 16) s when every step is its own launch
         per_rod_step = (25 * N + 4) * esize if persistent else (75 * N + 16) * esize
         launches = 1 if persistent else K
-        alg_bytes = B * per_rod_step * (K if persistent else 1)
+        units_per_launch = B * (K if persistent else 1)  # rod-steps one launch processes
+        alg_bytes = units_per_launch * per_rod_step
         kernel_ms = kernel_ms / launches
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        hbm_achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # SURVEY 8d algorithmic flops per rod-step: (N-1) (7k+1) F_ode with k = 3 Newton iterations, F_ode = 450
+        flops_per_rod_step = (N - 1) * 22 * 450
+        tf_achieved = units_per_launch * flops_per_rod_step / (kernel_ms * 1e-3) / 1e12
+        prof_hbm = committed_profile(B, N, args.dtype, path, "hbm")
+        prof_sq = committed_profile(B, N, args.dtype, path, "sq")
+        traffic = None
+        if prof_hbm:
+            per_unit = prof_hbm["hbm_bytes_per_launch_corrected"] / (B * prof_hbm.get("steps_per_launch", 1))
+            traffic = int(per_unit * units_per_launch)
+        valu_issue = None
+        if prof_sq and prof_sq.get("per_launch", {}).get("SQ_INSTS_VALU") and prof_sq.get("steps_per_launch"):
+            instr_per_unit = prof_sq["per_launch"]["SQ_INSTS_VALU"] / (B * prof_sq["steps_per_launch"])
+            # wave-instructions x 4 issue cycles over the SIMD-cycles of the launch (B <= 1024: one wavefront per SIMD)
+            valu_issue = round(instr_per_unit * units_per_launch * 4 / (min(B, SIMDS) * kernel_ms * 1e-3 * CLOCK_HZ), 4)
         out = {
             "metric": "rod-steps/sec (N=100 segments, batch=1024)",
             "value": round(rod_steps / elapsed, 1),
@@ -214,6 +283,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
+            "settle_steps": settle,
             "ms_per_step": round(elapsed / K * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -222,45 +292,49 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"forward simulate, B={B} rods/GPU, N={N}, Euler shooting + BDF2, NN off, "
-                            f"setup_robot(None), per-rod sine tensions rng(1235)",
+                            f"setup_robot(None), per-rod sine tensions rng({SEED})",
                 "rods_per_gpu": B, "N": N, "unconverged_rod_steps": n_bad,
             },
             "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic(B, N, args.dtype, path, K if persistent else 1),
+                "bound": "valu_fp64" if args.dtype == "f64" else "valu_issue",
+                "achieved": round(tf_achieved, 3),
+                "peak": FP64_VALU_PEAK_TF,
+                "unit": "TFLOP/s",
+                "frac": round(tf_achieved / FP64_VALU_PEAK_TF, 5),
+                "traffic": traffic,
+                "algorithmic_flops_per_rod_step": flops_per_rod_step,
+                "valu_issue_frac": valu_issue,
+                "hbm": {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes,
+                        "algorithmic_bytes_per_rod_step": per_rod_step},
                 "kernel": ("kr::ms_sim_kernel (persistent, all K steps in one launch)", "kr::ms_step_kernel",
                            "kr::step_kernel")[2 - path] if path in (0, 1, 2) else "?",
                 "kernel_ms": round(kernel_ms, 4),
                 "launches": launches,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "fp64 VALU issue bound, not HBM bound: one rod per wavefront on each of the 1024 SIMDs, "
-                        "2 Newton sweeps x 25 grid points x ~180 fp64 instructions per step; VALU busy ~58% of wave cycles "
-                        "(profiles/*pmc_sq.json, DESIGN.md section 4)",
+                "profile": {"hbm": prof_hbm and prof_hbm["_file"], "sq": prof_sq and prof_sq["_file"]},
+                "note": "one rod per wavefront on each of the 1024 SIMDs: the launch is bound by the fp64 vector "
+                        "issue rate of a single wave, not by HBM (counter traffic ~ the algorithmic bytes); `achieved` "
+                        "prices SURVEY 8d's algorithmic flops per rod-step against the fp64 vector peak, "
+                        "`valu_issue_frac` is measured VALU issue (SQ_INSTS_VALU x 4 cycles over SIMD-cycles, "
+                        "profiles/*pmc_sq.json), `hbm` the nominal roof of SURVEY 8d",
             },
         }
+        if cold is not None:
+            out["cold_start"] = {"unit": "rod-steps/s", **cold,
+                                 "note": "T steps from the straight rod in one call, no warm-up, no predictor hand-over "
+                                         "(SURVEY 8d cfg3: T=64, cfg2: T=200), best of 2"}
         if world == 1 and not args.no_cpu:
-            cb, tips = cpu_baseline(N, robot.del_t)
-            # tip parity of the GPU run against the oracle on the rods the CPU leg simulated (first steps)
-            import numpy as _np
-            Tc = tips[0].shape[0]
-            if Tc <= W + K:
-                st2 = h.new_state(len(tips), tdt, n_slots=3)
-                h.init_straight(st2[0])
-                G2 = torch.zeros((len(tips), 6), dtype=tdt, device=dev)
-                tip2 = torch.empty((len(tips), Tc, 3), dtype=tdt, device=dev)
-                c2 = torch.as_tensor(_np.stack([_cpu_ctl(b, Tc, robot.del_t) for b in range(len(tips))]), device=dev).to(tdt)
-                h.simulate(c2.contiguous(), st2, G2, ring=True, tip=tip2)
-                torch.cuda.synchronize()
-                g = tip2.cpu().numpy()
-                errs = [float(_np.linalg.norm(g[b] - tips[b]) / _np.linalg.norm(tips[b])) for b in range(len(tips))]
-                out["tip_rel_l2_vs_oracle"] = max(errs)
+            Tc = min(pre + K, max(50, pre + 20))
+            cb, tips = cpu_baseline(N, robot.del_t, B, Tc)
+            # tip parity of the TIMED batch against the oracle: same rods, same steps (untimed + first timed ones)
+            gpu_tips = torch.cat([tip_pre[:, :pre], tip], dim=1)[: len(tips), :Tc].double().cpu().numpy()
+            errs = [float(np.linalg.norm(gpu_tips[b] - tips[b]) / np.linalg.norm(tips[b])) for b in range(len(tips))]
+            out["tip_rel_l2_vs_oracle"] = max(errs)
+            out["tip_check"] = {"rods": len(tips), "steps": Tc, "timed_steps_included": max(0, Tc - pre),
+                                "what": "rods 0.. of the timed batch, steps 1..steps of their trajectory"}
             out["cpu_baseline"] = cb
             try:
-                out["cpu_baseline_c"] = cpu_baseline_c(N, robot.del_t)
+                out["cpu_baseline_c"] = cpu_baseline_c(N, robot.del_t, B)
             except Exception as e:  # the C restatement is optional test infrastructure (needs gcc or its prebuilt .so)
                 out["cpu_baseline_c"] = {"error": str(e)}
         print(json.dumps(out))
@@ -268,7 +342,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline_c(N, del_t, rods=256, steps=150):
+def cpu_baseline_c(N, del_t, B, rods=256, steps=150):
     """The scalar C restatement (oracle/cosserat_oracle_c.c, Newton shooting) on all host cores, one rod per call,
     threads (the C call releases the GIL): what an optimised CPU implementation of the same discrete equations
     reaches, beside the NumPy port that has the reference's own execution model."""
@@ -278,7 +352,7 @@ def cpu_baseline_c(N, del_t, rods=256, steps=150):
     import cosserat_oracle_c as oc
     cores = min(len(os.sched_getaffinity(0)), 16)
     P = orc.params_for(None, N)
-    ctl = orc.batch_sine_controls(rods, steps, del_t, 1235)
+    ctl = rank_controls(max(B, rods), 1, 0, steps, del_t)[:rods]
     oc.simulate(P, ctl[0][:4], traj=False)  # load + build outside the timed region
     t0 = time.perf_counter()
     one = oc.simulate(P, ctl[0], traj=False)
@@ -291,12 +365,6 @@ def cpu_baseline_c(N, del_t, rods=256, steps=150):
             "sample": f"{rods} rods x {steps} steps of the bench workload (N={N}, fp64), scalar C, Newton shooting to 1e-12, "
                       f"one rod per thread", "single_core_value": round(steps / t_single, 1),
             "unconverged": int(sum(r[2] for r in res) + one[2])}
-
-
-def _cpu_ctl(b, steps, del_t):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cosserat_oracle as orc
-    return orc.batch_sine_controls(max(b + 1, 16), steps, del_t, 1235)[b]
 
 
 if __name__ == "__main__":

@@ -120,12 +120,24 @@ class CosseratRod:
         else:
             self._handle.set_params(p)
         if self.nn_path is not None:
-            key = (id(self.nn_model), id(self.param_ls), bool(self.nn_input_history),
-                   tuple(float(np.asarray(p_).ravel()[0]) for p_ in self.param_ls))
-            if key != self._mlp_key:
-                self._handle.set_mlp(*mlp_from_layer_strings(self.nn_model, self.param_ls))
-                self._mlp_key = key
+            self._push_mlp(self.nn_model, self.param_ls)
         return self._handle
+
+    def _push_mlp(self, model, param_ls):
+        """Packs and uploads the network only when it changed: the key is a digest of every parameter byte and
+        of the layer strings, so repeated ``simulate`` / ``get_nn_output`` calls with the same weights reuse the
+        packed copies the handle already holds (kr_set_mlp allocates and copies synchronously)."""
+        import hashlib
+        dg = hashlib.blake2b(digest_size=16)
+        dg.update(("|".join(str(m) for m in model) + f"|{bool(self.nn_input_history)}").encode())
+        for p_ in param_ls:
+            a = np.ascontiguousarray(np.asarray(p_, dtype=np.float32))
+            dg.update(str(a.shape).encode())
+            dg.update(a.tobytes())
+        key = dg.digest()
+        if key != self._mlp_key:
+            self._handle.set_mlp(*mlp_from_layer_strings(model, param_ls))
+            self._mlp_key = key
 
     @property
     def _use_nn(self) -> bool:
@@ -150,9 +162,14 @@ class CosseratRod:
     def get_nn_output(self, input, model, param_ls):
         """Reference cosserat_ode.py:90-112, evaluated on the device in fp64."""
         import torch
-        h = self._native() if self._handle is None else self._handle
-        h.set_mlp(*mlp_from_layer_strings(model, param_ls))
-        self._mlp_key = None
+        if self._handle is None:
+            saved, self.nn_path = self.nn_path, None  # (the handle is created without pushing self.nn_model)
+            try:
+                self._native()
+            finally:
+                self.nn_path = saved
+        h = self._handle
+        self._push_mlp(model, param_ls)
         x = torch.as_tensor(np.asarray(input, dtype=np.float64).reshape(1, -1), device=f"cuda:{self.device}")
         return h.mlp_eval(x.contiguous())[0].cpu().numpy()
 

@@ -129,7 +129,10 @@ def simulate_batch(robot, ctl, dtype="f64", scheme="euler", return_states=True, 
 
 
 def simulate(robot, ctl, robot_reference=None):
-    """Reference knode.py:55-102."""
+    """Reference knode.py:55-102.  The time loop is one ``kr_simulate_batch`` call, the ``[y; z; yh; zh]`` rows of all
+    steps one ``kr_state_unpack50`` launch.  A step whose shooting solve did not converge raises a ``RuntimeWarning``
+    (the reference's ``fsolve`` does the same through SciPy and carries on)."""
+    import warnings
     import torch
     if robot_reference is None:
         robot_reference = robot
@@ -138,6 +141,8 @@ def simulate(robot, ctl, robot_reference=None):
     N = int(robot_reference.N)
     if int(robot.N) != N:
         raise kn.KrError("robot and robot_reference must share N")
+    if T == 0:  # np.array([initial])[:-1] in the reference
+        return np.empty((0, 50, N), dtype=np.float64)
     h = robot._native()
     dev = f"cuda:{robot.device}"
     states = h.new_state(1, torch.float64, n_slots=max(T, 2))
@@ -146,14 +151,22 @@ def simulate(robot, ctl, robot_reference=None):
         robot_reference._native().init_straight(states[0])
     else:
         h.init_straight(states[0])
+    status = None
     if T > 1:  # the T-th solve is dropped by the reference (knode.py:102), so it is not run
         G = torch.zeros((1, 6), dtype=torch.float64, device=dev)
+        status = torch.zeros((1, T - 1), dtype=torch.int32, device=dev)
         ctl_t = torch.as_tensor(ctl[: T - 1].reshape(1, T - 1, 4), device=dev).contiguous()
-        h.simulate(ctl_t, states, G, ring=False, use_nn=robot._use_nn)
-    out = torch.empty((T, 50, N), dtype=torch.float64, device=dev)
-    for t in range(T):
-        m1 = states[t - 1] if t >= 1 else states[0]
-        m2 = states[t - 2] if t >= 2 else states[0]
-        h.unpack50(states[t], m1, m2, out=out[t:t + 1])
+        h.simulate(ctl_t, states, G, ring=False, use_nn=robot._use_nn, status=status)
+    # entry t = [state t; c1 * state t-1 + c2 * state t-2] (knode.py:74-75,96): the T entries as one batch of T "rods"
+    st = states[:T, 0]
+    m1 = torch.cat([st[:1], st[: T - 1]])
+    m2 = torch.cat([st[:1], st[:1], st[: T - 2]]) if T > 1 else st[:1]
+    out = h.unpack50(st.contiguous(), m1.contiguous(), m2.contiguous())
     out[0, 25:] = out[0, :25]  # knode.py:68: entry 0 is vstack([y, z, y, z])
-    return out.cpu().numpy()
+    res = out.cpu().numpy()
+    if status is not None:
+        bad = np.flatnonzero(status.cpu().numpy()[0])
+        if bad.size:
+            warnings.warn(f"shooting solve did not converge at step(s) {bad[:8].tolist()}"
+                          f"{' ...' if bad.size > 8 else ''} of {T - 1}", RuntimeWarning)
+    return res

@@ -157,6 +157,9 @@ class KnodeTrainer:
             self.bucket.flat.zero_()
         else:
             self.optimizer = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay)
+            # the option lives on the robot's (shared) handle: an earlier native-Adam trainer may have left it on,
+            # and this branch relies on the library zeroing dW / db / loss itself
+            h.set_option("mlp_grad_accumulate", 0)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", patience=patience,
                                                                     factor=factor)
 
@@ -213,6 +216,56 @@ class KnodeTrainer:
         if sync_loss:
             self.scheduler.step(val)
         return val
+
+    def optimizer_state_dict(self):
+        """``torch.optim.Adam.state_dict()`` layout (what physics_train.py:284-288 stores under 'optim'): per
+        parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` plus one param group.  With the fused optimizer the moments
+        are views into its flat buffers, copied out here."""
+        if not self.native_adam:
+            return self.optimizer.state_dict()
+        state, off = {}, 0
+        for k, (p, sz) in enumerate(zip(self.params, self.bucket.sizes)):
+            if self.adam_step > 0:
+                state[k] = {"step": torch.tensor(float(self.adam_step)),
+                            "exp_avg": self.exp_avg[off:off + sz].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + sz].view(p.shape).clone()}
+            off += sz
+        group = {"lr": float(self.optimizer.param_groups[0]["lr"]), "betas": tuple(self.betas), "eps": self.adam_eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """Resume from an Adam ``state_dict`` (ours or one written by the reference's torch.optim.Adam)."""
+        if not self.native_adam:
+            self.optimizer.load_state_dict(sd)
+            return
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.params):
+            raise kn.KrError("optimizer state does not match the network (number of parameters)")
+        if group.get("amsgrad") or group.get("maximize"):
+            raise kn.KrError("only plain Adam state can be resumed (amsgrad / maximize are not implemented)")
+        self.betas, self.adam_eps = tuple(group["betas"]), float(group["eps"])
+        self.weight_decay = float(group["weight_decay"])
+        self.optimizer.param_groups[0]["lr"] = float(group["lr"])
+        steps, off = set(), 0
+        for k, (p, sz) in enumerate(zip(self.params, self.bucket.sizes)):
+            st = sd["state"].get(group["params"][k])
+            if st is None:
+                self.exp_avg[off:off + sz].zero_()
+                self.exp_avg_sq[off:off + sz].zero_()
+                steps.add(0)
+            else:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise kn.KrError(f"optimizer state of parameter {k} has shape {tuple(st['exp_avg'].shape)}")
+                self.exp_avg[off:off + sz].copy_(st["exp_avg"].reshape(-1).to(self.exp_avg))
+                self.exp_avg_sq[off:off + sz].copy_(st["exp_avg_sq"].reshape(-1).to(self.exp_avg_sq))
+                steps.add(int(float(st["step"])))
+            off += sz
+        if len(steps) != 1:
+            raise kn.KrError("per-parameter step counts differ: not a state the fused Adam can continue")
+        self.adam_step = steps.pop()
 
     def predictions(self):
         """[S, 25, K] predictions of the last forward pass (reference layout of grow_trajs)."""

@@ -8,7 +8,8 @@ evaluation :136-167, checkpoint :284-288), running on the MI355X kernels:
     (trajectory, window step, key point) row in one batch,
   * evaluation every 50 epochs: closed-loop rollout with the live weights (``krod_eval.evaluate``), exact DTW of the
     tip path against the validation reference (the reference uses ``fastdtw``, an approximation of it),
-  * checkpoint: ``torch.save({'robot', 'dtw', 'loss', 'optim'})`` - readable by the reference.
+  * checkpoint: ``torch.save({'robot', 'dtw', 'loss', 'optim'})`` - readable by the reference; ``optim`` is an
+    Adam ``state_dict`` (step, exp_avg, exp_avg_sq per parameter + param_groups), ``--resume`` continues from it.
 
 The printed lines ``Epoch {n} of {epochs}`` and ``Total loss: {x}, lr {[..]}`` are the ones
 ``physics_multitrain.py:113-121`` parses.  Under ``torch.distributed.run`` the trajectories are sharded over the
@@ -60,6 +61,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fast", action=argparse.BooleanOptionalAction, default=False)
     ap.add_argument("--save", type=str, default=None, help="checkpoint path (default: saved_models/<reference naming>)")
+    ap.add_argument("--resume", type=str, default=None,
+                    help="checkpoint to continue from (RESUME_TRAINING of physics_train.py:27,186-188,202-204)")
     args = ap.parse_args(argv)
 
     control_type, control_arg = split_list(args.control_type_arg)
@@ -99,6 +102,12 @@ def main(argv=None):
     robot = CosseratRodTorch(device, args.layers)                       # imperfect model + trainable MLP
     setup_robot(robot, args.mod)
 
+    resume = None
+    if args.resume:
+        import krod_checkpoint as kc
+        resume = kc.load_checkpoint(args.resume, device)
+        robot.nn_models.load_state_dict(resume["robot"].nn_models.state_dict())
+
     # training data (physics_train.py:98-134): one reference trajectory per control specification
     trajs, ctls = [], []
     for ct, ca in zip(control_type, control_arg):
@@ -111,11 +120,13 @@ def main(argv=None):
     traj_t = traj_t + torch.randn_like(traj_t) * args.noise_traj
     ctl_t = ctl_t + torch.randn_like(ctl_t) * args.noise_controls
     say("Total number of trajectories: ", len(trajs))
+    # more ranks than trajectories: the surplus ranks hold an EMPTY shard and contribute zeros to the summed
+    # gradient and loss (KnodeTrainer and the C API accept Q = 0), so the result equals the single-process one
     lo, hi = shard_range(len(trajs), rank, world)
-    if hi == lo:  # more ranks than trajectories: every rank needs at least one row block
-        lo, hi = 0, 1
     key_pt_idx = [3, 5, 7, 9] if args.fast else [2, 6, 9]   # physics_train.py:312 / :216-220
     trainer = KnodeTrainer(robot, traj_t[lo:hi], ctl_t[lo:hi], key_pt_idx, weight_decay=args.weight_decay)
+    if resume is not None and resume.get("optim"):
+        trainer.load_optimizer_state_dict(resume["optim"])
 
     validation_controls = np.array(calc_controls(validation_type, validation_arg, robot_reference.del_t, eval_len))
     validation_reference = simulate(robot_reference, validation_controls)[:, :25] if (args.eval and rank == 0) else None
@@ -139,7 +150,8 @@ def main(argv=None):
         os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
         if best[1] is not None:
             robot.nn_models.load_state_dict(best[1])   # physics_train.py:410-417 keeps the best-DTW snapshot
-        torch.save({"robot": robot, "dtw": dtw_arr, "loss": loss_arr, "optim": trainer.optimizer.state_dict()}, save_path)
+        # 'optim': torch.optim.Adam's state_dict layout (physics_train.py:284-288), filled from the fused optimizer
+        torch.save({"robot": robot, "dtw": dtw_arr, "loss": loss_arr, "optim": trainer.optimizer_state_dict()}, save_path)
         say("saved", save_path)
     if world > 1:
         dist.destroy_process_group()

@@ -317,29 +317,46 @@ def straight_state(D: Derived):
     return y, z
 
 
-def newton_shoot(fun, G0, tol=1e-12, maxit=50, fd_eps=1e-7):
-    """Plain Newton on the 6 shooting unknowns with a forward-difference
-    Jacobian; the stopping rule is on the Newton update.  ``fun`` must leave
-    the swept state at the point it was last called with, so after convergence
-    one more call at the accepted ``G`` leaves the caller's y, z consistent."""
+def newton_shoot(fun, G0, tol=1e-12, maxit=50, fd_eps=1e-7, damped=True):
+    """Newton on the 6 shooting unknowns with a forward-difference Jacobian; the
+    stopping rule is on the Newton update.  ``damped``: a step that does not
+    reduce the residual norm is halved until it does (backtracking) - where the
+    full step already reduces it, which is every step of every fixture but the
+    untrained 512-wide network, the iterates are those of plain Newton.  ``fun``
+    must leave the swept state at the point it was last called with, so after
+    convergence one more call at the accepted ``G`` leaves the caller's y, z
+    consistent."""
     G = np.array(G0, float)
     it = 0
     ok = False
+    r0 = fun(G)
     for it in range(1, maxit + 1):
-        r0 = fun(G)
         Jm = np.empty((6, 6))
         for c in range(6):
             e = fd_eps * max(abs(G[c]), 1.0)
             Gp = G.copy()
             Gp[c] += e
             Jm[:, c] = (fun(Gp) - r0) / e
-        d = np.linalg.solve(Jm, r0)
+        with np.errstate(all="ignore"):
+            try:
+                d = np.linalg.solve(Jm, r0)
+            except np.linalg.LinAlgError:
+                break
         if not np.all(np.isfinite(d)):
             break
         if np.max(np.abs(d)) <= tol * max(1.0, np.max(np.abs(G))):
             ok = True
             break
-        G = G - d
+        lam, n0 = 1.0, np.linalg.norm(r0)
+        while True:
+            with np.errstate(all="ignore"):
+                r1 = fun(G - lam * d)
+            n1 = np.linalg.norm(r1)
+            if not damped or (np.isfinite(n1) and n1 <= n0 * (1.0 - 1e-4 * lam)) or lam < 1e-4:
+                break
+            lam *= 0.5
+        G = G - lam * d
+        r0 = r1
     fun(G)  # final sweep at the accepted point
     return G, ok, it
 
@@ -350,7 +367,7 @@ def simulate(D: Derived, ctl, mlp: Mlp | None = None, scheme: str = "euler", sol
 
     ``solver='fsolve'`` is the reference's own choice (MINPACK hybrd through
     SciPy, knode.py:89); the returned y, z are whatever the last residual call
-    left behind.  ``solver='newton'`` is the tightly converged variant the HIP
+    left behind.  ``solver='lbfgs'`` is its ``use_fsolve=False`` branch.  ``solver='newton'`` is the tightly converged variant the HIP
     kernels implement.  Output: ``float64[T, 50, N]`` with rows
     ``[y; z; yh; zh]``; entry 0 is the initial state and the last solved step
     is dropped (knode.py:102)."""
@@ -378,6 +395,14 @@ def simulate(D: Derived, ctl, mlp: Mlp | None = None, scheme: str = "euler", sol
             G, fo, ier, _ = fsolve(fun, G, full_output=True, xtol=xtol)
             info["ier"].append(ier)
             info["nfev"].append(fo["nfev"])
+        elif solver == "lbfgs":
+            # the use_fsolve=False branch, knode.py:91-94: L-BFGS-B on the sum of squared residuals
+            # (cosserat_ode.py:212-213); y, z are left at the minimiser's last function call
+            from scipy.optimize import minimize
+            res = minimize(lambda g: float(np.sum(fun(g) ** 2)), G, method="L-BFGS-B")
+            G = res.x
+            info["ier"].append(1 if res.success else 5)
+            info["nfev"].append(res.nfev)
         else:
             G, ok, it = newton_shoot(fun, G, tol=tol)
             info["ier"].append(1 if ok else 5)

@@ -473,6 +473,72 @@ def gen_estimate_state():
     save("estimate_state", **out)
 
 
+def gen_sim_more():
+    """Round-2 additions: (a) the reference's DEFAULT network 28 -> 512 -> 25 (cosserat_ode_torch.py:60-62,
+    physics_train.py:47) inside simulate; (b) BASELINE cfg5 inputs: N=400 under calc_controls('sine', P) for
+    P in {0.5, 2, 3} (P=1: sim_n400.npz); (c) the use_fsolve=False branch of knode.simulate (knode.py:91-94,
+    L-BFGS-B on the sum of squares); (d) the torch twin's differentiable full sweep getResidualEuler(G)
+    (cosserat_ode_torch.py:325-367), NN off and on."""
+    out = {}
+    # "elu512": weights exactly as the reference initialises them - with 512 all-positive hidden units the untrained
+    # correction moves the tip by 85 % and plain Newton from the warm start diverges from step 10 on (hybrd's trust
+    # region copes): pins the damped fallback of the solver.  "elu512n24": the same network at 0.3 x the weights.
+    for name, N, T, wscale in (("elu512", 10, 30, 1.0), ("elu512n24", 24, 12, 0.3)):
+        mlp = orc.make_mlp([28, 512, 25], "elu", seed=3)
+        mlp.weights = [(w * wscale).astype(np.float32) for w in mlp.weights]
+        r = np_robot(None, N)
+        inject_nn(r, mlp)
+        ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, T)
+        traj, ier, nfev = run_sim(r, ctl)
+        out[f"{name}_ctl"], out[f"{name}_traj"], out[f"{name}_ier"] = np.array(ctl), traj[:, :25], ier
+        out[f"{name}_N"] = np.array(N)
+        out.update(mlp_arrays(f"mlp_{name}", mlp))
+    for P in (0.5, 2.0, 3.0):
+        r = np_robot(None, 400)
+        ctl = ref_ctl.calc_controls("sine", P, r.del_t, 8)
+        traj, ier, nfev = run_sim(r, ctl)
+        tag = f"n400_P{P}".replace(".", "_")
+        out[f"{tag}_ctl"], out[f"{tag}_tip"], out[f"{tag}_last"], out[f"{tag}_ier"] = (
+            np.array(ctl), traj[:, :3, -1], traj[-1, :25], ier)
+    # (c) minimize branch: the reference's own driver loop, unmodified
+    r = np_robot(None, 10, use_fsolve=False)
+    ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, 12)
+    with np.errstate(all="ignore"):
+        traj = ref_knode.simulate(r, ctl)
+    out["lbfgs_ctl"], out["lbfgs_traj"] = np.array(ctl), traj
+    # (d) torch getResidualEuler(G): state of a short run, G slightly off the root
+    rn = np_robot(None, 10)
+    y, z, yp, zp, G0, tens = converged_state(rn, 6, lambda T: ref_ctl.calc_controls("sine", 1.0, rn.del_t, T))
+    mlp = orc.make_mlp([28, 64, 25], "elu", seed=11)
+    mlp.weights = [w * 3 for w in mlp.weights]
+    out.update(mlp_arrays("mlp_tres", mlp))
+    out["tres_y"], out["tres_z"], out["tres_yp"], out["tres_zp"], out["tres_tens"] = y, z, yp, zp, tens
+    Gs = np.stack([G0, G0 * 1.03 + 1e-3])
+    out["tres_G"] = Gs
+    for use_nn in (0, 1):
+        rob = ref_torch.CosseratRodTorch("cpu", 64)
+        ref_knode.setup_robot(rob, None)
+        rob.nn_models = torch_module_list(mlp)
+        rob.use_nn = bool(use_nn)
+        ty, tz = torch.tensor(y).float(), torch.tensor(z).float()
+        typ, tzp = torch.tensor(yp).float(), torch.tensor(zp).float()
+        vals, rods, ys = [], [], []
+        for G in Gs:
+            rob.y, rob.z = ty.clone(), tz.clone()
+            rob.tendon_tensions = torch.tensor(tens).float()
+            rob.residualArgs["yh"] = rob.c1 * ty + rob.c2 * typ
+            rob.residualArgs["zh"] = rob.c1 * tz + rob.c2 * tzp
+            with torch.no_grad():
+                tot, full = rob.getResidualEuler(torch.tensor(G).float())
+            vals.append(float(tot))
+            rods.append(full.numpy())
+            ys.append(rob.y.numpy().copy())
+        out[f"tres_val_{use_nn}"] = np.array(vals)
+        out[f"tres_full_{use_nn}"] = np.array(rods)
+        out[f"tres_yafter_{use_nn}"] = np.array(ys)
+    save("sim_more", **out)
+
+
 def gen_small():
     """F8: calc_controls and quaternion_to_euler."""
     out = {}
@@ -493,7 +559,7 @@ def gen_small():
 ALL = {
     "ode_kat": gen_ode_kat, "ode_torch_kat": gen_ode_torch_kat, "residual_kat": gen_residual_kat,
     "sim_cfg1": gen_sim_cfg1, "sim_n100": gen_sim_n100, "sim_n400": gen_sim_n400, "sim_misc": gen_sim_misc,
-    "sim_nn": gen_sim_nn, "train_step": gen_train_step, "small": gen_small,
+    "sim_nn": gen_sim_nn, "sim_more": gen_sim_more, "train_step": gen_train_step, "small": gen_small,
     "checkpoint": gen_checkpoint, "estimate_state": gen_estimate_state,
 }
 

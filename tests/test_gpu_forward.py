@@ -30,44 +30,24 @@ def torch_cuda():
     return torch
 
 
-@pytest.fixture(autouse=True, params=["single", "multi", "persistent"])
+from gpu_helpers import MODES, assert_path, inject, make_robot, require_path, set_mode_env  # noqa: E402
+
+
+@pytest.fixture(autouse=True, params=MODES)
 def shooting_mode(request, monkeypatch):
     """Every test runs three times: with the single-shooting step kernel (8 rods per wavefront), with
     the multiple-shooting one (1 rod per wavefront, one launch per step) and with its persistent form
-    (all steps of kr_simulate_batch in one launch), forced wherever they are eligible.  kr_create
-    reads KR_MS_MODE / KR_PERSISTENT."""
-    monkeypatch.setenv("KR_MS_MODE", "0" if request.param == "single" else "1")
-    monkeypatch.setenv("KR_PERSISTENT", "1" if request.param == "persistent" else "0")
+    (all steps of kr_simulate_batch in one launch).  Tests that simulate call ``require_path`` (skips the
+    parametrisation when the named kernel cannot serve the problem) and ``assert_path`` (what ran)."""
+    set_mode_env(monkeypatch, request.param)
     return request.param
 
 
-def make_robot(mod, N, use_fsolve=True):
-    from cosserat_ode import CosseratRod
-    from knode import setup_robot
-    r = CosseratRod(use_fsolve=use_fsolve)
-    if mod != "default":
-        setup_robot(r, mod)
-    r.N = N
-    r.compute_intermediate_terms()
-    return r
-
-
-def inject(robot, mlp):
-    """What physics_train.py:104-110 does, with plain strings standing in for the torch modules
-    (the reference only ever looks at str(layer))."""
-    import cosserat_oracle as orc
-    names = {orc.ACT_TANH: "Tanh()", orc.ACT_SOFTPLUS: "Softplus(beta=1.0, threshold=20.0)",
-             orc.ACT_RELU: "ReLU()", orc.ACT_ELU: "ELU(alpha=1.0)"}
-    model, params = [], []
-    for W, b, a in zip(mlp.weights, mlp.biases, mlp.acts):
-        model.append(f"Linear(in_features={W.shape[1]}, out_features={W.shape[0]}, bias=True)")
-        params += [W, b]
-        if a != orc.ACT_NONE:
-            model.append(names[a])
-    robot.nn_model = model
-    robot.param_ls = params
-    robot.nn_path = "whatever"
-    robot.nn_input_history = mlp.history
+def _once(mode):
+    """Kernels that take no time step (batched ODE, residual sweeps, MLP rows) do not depend on the step-kernel
+    mode: run under one parametrisation only."""
+    if mode != "single":
+        pytest.skip("independent of the step-kernel mode")
 
 
 # ---------------------------------------------------------------------------
@@ -83,7 +63,8 @@ def _ode_rows_gpu(torch, robot, g, dtype):
 
 
 @pytest.mark.parametrize("mod", MODS)
-def test_ode_batch_presets_f64(torch_cuda, mod):
+def test_ode_batch_presets_f64(torch_cuda, shooting_mode, mod):
+    _once(shooting_mode)
     g = load_golden("ode_kat")
     got = _ode_rows_gpu(torch_cuda, make_robot(mod, 10), g, torch_cuda.float64)
     ref = g[f"phys_{mod}"]
@@ -92,7 +73,8 @@ def test_ode_batch_presets_f64(torch_cuda, mod):
 
 
 @pytest.mark.parametrize("name", NN)
-def test_ode_batch_mlp_f64(torch_cuda, name):
+def test_ode_batch_mlp_f64(torch_cuda, shooting_mode, name):
+    _once(shooting_mode)
     import cosserat_oracle as orc
     g = load_golden("ode_kat")
     r = make_robot(None, 10)
@@ -103,8 +85,9 @@ def test_ode_batch_mlp_f64(torch_cuda, name):
 
 @pytest.mark.parametrize("name", ["elu64", "hist64", "elu6464"])
 @pytest.mark.parametrize("use_nn", [0, 1])
-def test_ode_batch_f32_vs_torch_twin(torch_cuda, name, use_nn):
+def test_ode_batch_f32_vs_torch_twin(torch_cuda, shooting_mode, name, use_nn):
     """fp32 kernel against CosseratRodTorch.ODE_parallel / ODE outputs."""
+    _once(shooting_mode)
     import cosserat_oracle as orc
     g = load_golden("ode_kat")
     gt = load_golden("ode_torch_kat")
@@ -119,7 +102,8 @@ def test_ode_batch_f32_vs_torch_twin(torch_cuda, name, use_nn):
     assert rel_l2(got, ref) < 2e-6
 
 
-def test_ode_single_row_method(torch_cuda):
+def test_ode_single_row_method(torch_cuda, shooting_mode):
+    _once(shooting_mode)
     g = load_golden("ode_kat")
     r = make_robot(None, 10)
     i = 7
@@ -128,8 +112,9 @@ def test_ode_single_row_method(torch_cuda):
     assert rel_l2(np.concatenate([ys, z]), g["phys_None"][i]) < 1e-13
 
 
-def test_ode_ragged_sizes(torch_cuda):
+def test_ode_ragged_sizes(torch_cuda, shooting_mode):
     """Q not a multiple of the tile, Q = 1, Q = 0."""
+    _once(shooting_mode)
     torch = torch_cuda
     g = load_golden("ode_kat")
     r = make_robot(None, 10)
@@ -155,7 +140,8 @@ def test_ode_ragged_sizes(torch_cuda):
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["N10_None", "N20_None", "N100_None", "N10_default", "N40_default"])
 @pytest.mark.parametrize("scheme", ["euler", "rk4"])
-def test_residual_methods(torch_cuda, tag, scheme):
+def test_residual_methods(torch_cuda, shooting_mode, tag, scheme):
+    _once(shooting_mode)
     g = load_golden("residual_kat")
     N = int(tag.split("_")[0][1:])
     mod = tag.split("_")[1]
@@ -187,23 +173,27 @@ def test_residual_methods(torch_cuda, tag, scheme):
 # ---------------------------------------------------------------------------
 # simulate
 # ---------------------------------------------------------------------------
-def test_simulate_cfg1(torch_cuda):
+def test_simulate_cfg1(torch_cuda, shooting_mode):
     """BASELINE config 1: single rod, N=20, 200 steps, tensions [6,5,5,6]."""
     from knode import simulate
     g = load_golden("sim_cfg1")
+    want = require_path(shooting_mode, 20)
     r = make_robot(None, 20)
     traj = simulate(r, g["ctl"])
+    assert_path(r, want)
     assert traj.shape == (200, 50, 20) and traj.dtype == np.float64
     assert rel_l2(traj[:, :3, -1], g["tip"]) < 1e-8
     assert rel_l2(traj[::10, :25], g["every10"]) < 1e-7
     assert rel_l2(traj[-1], g["last"]) < 1e-7
 
 
-def test_simulate_full50_layout(torch_cuda):
+def test_simulate_full50_layout(torch_cuda, shooting_mode):
     from knode import simulate
     g = load_golden("sim_misc")
+    want = require_path(shooting_mode, 10)
     r = make_robot(None, 10)
     traj = simulate(r, g["full50_ctl"])
+    assert_path(r, want)
     ref = g["full50_traj"]
     assert traj.shape == ref.shape
     assert np.array_equal(traj[0], ref[0])  # initial entry incl. its [y;z;y;z] quirk
@@ -212,32 +202,39 @@ def test_simulate_full50_layout(torch_cuda):
 
 
 @pytest.mark.parametrize("mod", MODS[2:] + ["default"])
-def test_simulate_presets(torch_cuda, mod):
+def test_simulate_presets(torch_cuda, shooting_mode, mod):
     from knode import simulate
     g = load_golden("sim_misc")
+    want = require_path(shooting_mode, 10)
     r = make_robot(mod, 10)
     traj = simulate(r, g[f"mod_{mod}_ctl"])
+    assert_path(r, want)
     assert rel_l2(traj[:, :25], g[f"mod_{mod}_traj"]) < 1e-8
 
 
 @pytest.mark.parametrize("kind", ["step", "random"])
-def test_simulate_inputs(torch_cuda, kind):
+def test_simulate_inputs(torch_cuda, shooting_mode, kind):
     from knode import simulate
     g = load_golden("sim_misc")
+    want = require_path(shooting_mode, 10)
     r = make_robot(None, 10)
     traj = simulate(r, g[f"{kind}_ctl"])
+    assert_path(r, want)
     assert rel_l2(traj[:, :25], g[f"{kind}_traj"]) < 1e-8
 
 
-def test_simulate_n100_and_batch(torch_cuda):
+def test_simulate_n100_and_batch(torch_cuda, shooting_mode):
     from knode import simulate, simulate_batch
     g = load_golden("sim_n100")
+    want = require_path(shooting_mode, 100)
     r = make_robot(None, 100)
     traj = simulate(r, g["ctl"])
+    assert_path(r, want)
     assert rel_l2(traj[:, :3, -1], g["tip"]) < 1e-8
     assert rel_l2(traj[::10, :25], g["every10"]) < 1e-7
     # cfg2-style batch: 6 rods with random phase / period, compared rod by rod
     out = simulate_batch(r, g["batch_ctl"])
+    assert_path(r, want)
     assert np.all(out["status"] == 0)
     ref = g["batch_tip"]  # [B, T, 3], entry 0 = initial tip, entry t = after step t
     got = out["traj"][:, : ref.shape[1], :3, -1]
@@ -247,43 +244,53 @@ def test_simulate_n100_and_batch(torch_cuda):
     assert np.array_equal(out["tip"], out["traj"][:, 1:, :3, -1])
     # fp32 arithmetic stays inside the 1e-5 contract
     out32 = simulate_batch(r, g["batch_ctl"], dtype="f32")
+    assert_path(r, want)
     assert np.all(out32["status"] == 0)
     for b in range(ref.shape[0]):
         assert rel_l2(out32["traj"][b, : ref.shape[1], :3, -1], ref[b]) < 1e-5
 
 
-def test_simulate_n400(torch_cuda):
-    """N=400 does not fit the LDS history buffer: exercises the global-history path."""
+def test_simulate_n400(torch_cuda, shooting_mode):
+    """N=400: the single-shooting kernel takes its history from global scratch (8 rods x 400 points do not fit
+    the LDS), the multiple-shooting kernel runs one or two rods per workgroup."""
     from knode import simulate
     g = load_golden("sim_n400")
+    want = require_path(shooting_mode, 400)
     r = make_robot(None, 400)
     traj = simulate(r, g["ctl"])
+    assert_path(r, want)
     assert rel_l2(traj[:, :3, -1], g["tip"]) < 1e-8
     assert rel_l2(traj[-1, :25], g["last"]) < 1e-7
 
 
-def test_simulate_rk4(torch_cuda):
+def test_simulate_rk4(torch_cuda, shooting_mode):
     from knode import simulate_batch
     g = load_golden("sim_misc")
+    want = require_path(shooting_mode, 40, scheme="rk4")
     r = make_robot(None, 40)
     ctl = g["rk4_ctl"]
     out = simulate_batch(r, ctl[None], scheme="rk4")
+    assert_path(r, want)
     ref = g["rk4_traj"]  # [T, 25, N] entries 0..T-1
     assert rel_l2(out["traj"][0, : ref.shape[0]], ref) < 1e-7
 
 
 @pytest.mark.parametrize("name", ["elu64", "elu6464", "hist64"])
-def test_simulate_with_mlp(torch_cuda, name):
+def test_simulate_with_mlp(torch_cuda, shooting_mode, name):
     import cosserat_oracle as orc
     from knode import simulate
     g = load_golden("sim_nn")
+    mlp = orc.mlp_from_arrays(g, f"mlp_{name}")
+    want = require_path(shooting_mode, int(g[f"{name}_N"]), mlp)
     r = make_robot(None, int(g[f"{name}_N"]))
-    inject(r, orc.mlp_from_arrays(g, f"mlp_{name}"))
+    inject(r, mlp)
     traj = simulate(r, g[f"{name}_ctl"])
+    assert_path(r, want)
     assert rel_l2(traj[:, :25], g[f"{name}_traj"]) < 1e-8
 
 
-def test_get_nn_output(torch_cuda):
+def test_get_nn_output(torch_cuda, shooting_mode):
+    _once(shooting_mode)
     import cosserat_oracle as orc
     g = load_golden("ode_kat")
     mlp = orc.mlp_from_arrays(g, "mlp_tanh6464")
@@ -301,6 +308,7 @@ def test_full_size_properties(torch_cuda, shooting_mode):
     torch = torch_cuda
     import cosserat_oracle as orc
     import krod_native as kn
+    want = require_path(shooting_mode, 100)
     r = make_robot(None, 100)
     h = r._native()
     B, T = 1024, 6
@@ -314,6 +322,7 @@ def test_full_size_properties(torch_cuda, shooting_mode):
     tip = torch.empty((B, T, 3), dtype=torch.float64, device=dev)
     h.simulate(ctl_t, states, G, tip=tip, status=status)
     torch.cuda.synchronize()
+    assert_path(h, want)
     assert int((status != 0).sum()) == 0
     # (1) the stored state is a root of the shooting residual: re-sweeping from the returned G
     #     reproduces it bit for bit and leaves a tiny residual
@@ -341,12 +350,14 @@ def test_full_size_properties(torch_cuda, shooting_mode):
 
 
 @pytest.mark.parametrize("kind", ["sine_fast", "step", "random"])
-def test_adaptive_predictor_on_rough_inputs(torch_cuda, kind):
+def test_adaptive_predictor_on_rough_inputs(torch_cuda, shooting_mode, kind):
     """The persistent kernel extrapolates the unknowns in time with an order (<= 7) it picks per rod and
     step.  On inputs that are not smooth (a jump; fresh random tensions every step, physics_controls.py:
     22-30) it has to fall back to low orders: every step must still converge, to the same states as the
     reference's plain warm start (predictor 0, one launch per step)."""
     torch = torch_cuda
+    if shooting_mode != "persistent":
+        pytest.skip("compares the persistent kernel with the per-step one itself")
     r = make_robot(None, 40)
     h = r._native()
     B, T = 16, 90
@@ -376,6 +387,7 @@ def test_adaptive_predictor_on_rough_inputs(torch_cuda, kind):
         status = torch.full((B, T), -1, dtype=torch.int32, device=dev)
         h.simulate(ctl_t, st, G, status=status)
         torch.cuda.synchronize()
+        assert_path(h, 2 if persistent else 1)
         assert int((status != 0).sum()) == 0
         outs.append(st[..., :25].cpu().numpy())
     for t in (1, 29, 31, 35, 61, T):  # all solves stop at |update| <= 1e-8: agreement at that level
@@ -383,7 +395,8 @@ def test_adaptive_predictor_on_rough_inputs(torch_cuda, kind):
         assert rel_l2(outs[1][t], outs[2][t]) < 1e-7
 
 
-def test_error_paths(torch_cuda):
+def test_error_paths(torch_cuda, shooting_mode):
+    _once(shooting_mode)
     torch = torch_cuda
     import krod_native as kn
     from knode import setup_robot
@@ -406,7 +419,7 @@ def test_error_paths(torch_cuda):
     h.step(st[0][:0], st[1][:0], st[2][:0], G[:0], tens[:0])
 
 
-def test_simulate_legacy_preset(torch_cuda):
+def test_simulate_legacy_preset(torch_cuda, shooting_mode):
     """prepare.py:35-73 parameters (del_t 0.005, steel rod): forward simulation against the oracle."""
     import cosserat_oracle as orc
     from cosserat_ode import CosseratRod
@@ -421,7 +434,9 @@ def test_simulate_legacy_preset(torch_cuda):
     T = 40
     ctl = np.array(orc.calc_controls("sine", 0.5, P.del_t, T))
     want = orc.simulate(P.derived(), ctl, solver="fsolve")
+    path = require_path(shooting_mode, 20)
     got = simulate(r, ctl)
+    assert_path(r, path)
     assert rel_l2(got[:, :25], want[:, :25]) < 1e-8
 
 
@@ -462,7 +477,7 @@ def test_keep_predictor_chunked_calls(torch_cuda, shooting_mode):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_randomized_parity_vs_oracle(torch_cuda, seed):
+def test_randomized_parity_vs_oracle(torch_cuda, shooting_mode, seed):
     """Seeded sweep over what the fixed fixtures do not vary together: preset, grid size (odd sizes, sizes around
     the multiple-shooting threshold), batch size, control type and MLP on/off - GPU batch vs the oracle (its tight
     Newton solver; the oracle itself is pinned to the reference's fsolve runs by tests/test_oracle_golden.py)."""
@@ -489,7 +504,9 @@ def test_randomized_parity_vs_oracle(torch_cuda, seed):
             ctl[b] = np.array(orc.calc_controls("step", float(rng.uniform(0.5, 2.0)), r.del_t, 40))[-T:]
         else:
             ctl[b] = 5.0 + 2.0 * rng.uniform(size=(T, 4))
+    path = require_path(shooting_mode, N, mlp)
     out = simulate_batch(r, ctl)
+    assert_path(r, path)
     assert np.all(out["status"] == 0), (mod, N, B, T, kind)
     D = orc.params_for(mod, N).derived()
     for b in range(B):

@@ -398,3 +398,54 @@ def test_training_driver_end_to_end(torch_cuda, tmp_path, capsys):
     assert len(ck["loss"]) == 60 and len(ck["robot"].nn_models) == 3
     assert ck["robot"].nn_models[0].weight.shape == (32, 28)
     assert float(ck["robot"].nn_models[0].weight.detach().min()) >= 0.0  # the clamp of physics_train.py:299-304
+
+
+def test_data_parallel_more_ranks_than_trajectories(torch_cuda, tmp_path):
+    """train_knode.py under torch.distributed.run with 3 ranks sharing the GPU (gloo) and only 2 trajectories: one rank
+    holds an empty shard and must contribute zeros, so the loss curve equals the single-process one (round 1 gave
+    idle ranks trajectory 0 again).  Also: the checkpoint carries real Adam state and training resumes from it."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import PKG
+    torch = torch_cuda
+    env = dict(os.environ, PYTHONPATH=PKG, KR_DIST_BACKEND="gloo")
+    common = ["sine", "random", "2", "7", "--fast", "--mod", "damping", "--epochs", "31", "--layers", "32", "--no-eval"]
+    script = os.path.join(PKG, "train_knode.py")
+
+    def losses(cmd, save):
+        out = subprocess.run(cmd + common + ["--save", save], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        vals = [float(m) for m in re.findall(r"Total loss: ([-0-9.e]+)", out.stdout)]
+        assert len(vals) == 4, out.stdout
+        return vals
+
+    one = losses([sys.executable, script], str(tmp_path / "one.pth"))
+    port = str(29600 + os.getpid() % 300)
+    three = losses([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                    "--master-addr", "127.0.0.1", "--master-port", port, script], str(tmp_path / "three.pth"))
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(one, three)), (one, three)
+    # the checkpoint's 'optim' entry is an Adam state_dict a torch.optim.Adam accepts
+    import krod_checkpoint as kc
+    ck = kc.load_checkpoint(str(tmp_path / "one.pth"), DEV)
+    sd = ck["optim"]
+    params = list(ck["robot"].nn_models.parameters())
+    assert len(sd["state"]) == len(params) == 4
+    assert all(float(sd["state"][k]["step"]) == 31 and sd["state"][k]["exp_avg"].shape == params[k].shape
+               and float(sd["state"][k]["exp_avg_sq"].abs().sum()) > 0 for k in range(4))
+    torch.optim.Adam(params, lr=1e-2).load_state_dict(sd)
+    # resuming continues the loss curve: 31 + 10 epochs == 41 epochs in one go (epoch 40's line is the last printed)
+    def run(extra, epochs, save):
+        cmd = [sys.executable, script] + [c if c != "31" else str(epochs) for c in common] + ["--save", save] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return [float(m) for m in re.findall(r"Total loss: ([-0-9.e]+)", out.stdout)]
+    full = run([], 41, str(tmp_path / "full.pth"))
+    cont = run(["--resume", str(tmp_path / "one.pth")], 10, str(tmp_path / "cont.pth"))
+    assert len(full) == 5 and len(cont) == 1  # (epoch numbering restarts after a resume: compare the end states)
+    ck_full = kc.load_checkpoint(str(tmp_path / "full.pth"), DEV)
+    ck_cont = kc.load_checkpoint(str(tmp_path / "cont.pth"), DEV)
+    assert abs(ck_cont["loss"][-1] - ck_full["loss"][-1]) <= 1e-4 * abs(ck_full["loss"][-1])
+    for a, b in zip(ck_cont["robot"].nn_models.parameters(), ck_full["robot"].nn_models.parameters()):
+        assert rel_l2(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-4

@@ -196,43 +196,71 @@ def test_shard_range_and_bucket():
 _DIST_WORKER = r"""
 import os, sys
 sys.path.insert(0, os.path.join(sys.argv[1], "knode-cosserat_amd"))
+sys.path.insert(0, sys.argv[1])
+import numpy as np
 import torch, torch.distributed as dist
 from krod_train import FlatBucket, shard_range
-dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+world, n_traj = int(sys.argv[4]), int(sys.argv[5])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=world)
 rank = dist.get_rank()
 shapes = [(64, 28), (64,), (25, 64), (25,)]
 b = FlatBucket(shapes, "cpu")
 assert b.flat.numel() == 64 * 28 + 64 + 25 * 64 + 25 + 1
-# every rank contributes gradients of its own trajectory shard: value = global trajectory index
-lo, hi = shard_range(7, rank, 2)
+# every rank contributes the gradients of its own trajectory shard (value = 1 + global trajectory index); a rank whose
+# shard is empty (more ranks than trajectories) contributes zeros - train_knode.py hands KnodeTrainer the empty shard
+lo, hi = shard_range(n_traj, rank, world)
 for v in b.views:
-    v.fill_(float(sum(range(lo, hi))))
+    v.fill_(float(sum(t + 1 for t in range(lo, hi))))
 b.loss.fill_(float(hi - lo))
 b.all_reduce()
-assert all(float(v.min()) == float(v.max()) == float(sum(range(7))) for v in b.views), "sum over ranks"
-assert float(b.loss) == 7.0
+total = float(sum(t + 1 for t in range(n_traj)))
+assert all(float(v.min()) == float(v.max()) == total for v in b.views), "sum over ranks"
+assert float(b.loss) == float(n_traj)
 # parameters that start identical and see the same reduced gradient stay identical
 p = torch.nn.Parameter(torch.ones(64, 28)); p.grad = b.views[0]
 opt = torch.optim.Adam([p], lr=1e-2); opt.step()
-ref = [torch.zeros_like(p) for _ in range(2)]
+ref = [torch.zeros_like(p) for _ in range(world)]
 dist.all_gather(ref, p.detach())
-assert torch.equal(ref[0], ref[1])
+assert all(torch.equal(ref[0], r) for r in ref)
+# bench.py shards the global batch of rods: rank r simulates rods [r B, (r + 1) B) of the world x B draw
+import bench
+B, steps = 5, 7
+mine = torch.as_tensor(bench.rank_controls(B, world, rank, steps, 0.05))
+parts = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(parts, mine)
+whole = torch.as_tensor(bench.rank_controls(B * world, 1, 0, steps, 0.05))
+assert torch.equal(torch.cat(parts), whole), "per-rank slices tile the global batch"
+assert mine.shape == (B, steps, 4) and not torch.equal(parts[0], parts[-1])
 dist.destroy_process_group()
 print("ok", rank)
 """
 
 
-def test_data_parallel_allreduce_gloo(tmp_path):
-    """world_size 2 over gloo on CPU: one flat all-reduce carries every gradient and the loss."""
+@pytest.mark.parametrize("world,n_traj", [(2, 7), (3, 2)])
+def test_data_parallel_allreduce_gloo(tmp_path, world, n_traj):
+    """gloo on CPU, world_size 2 (7 trajectories) and 3 (2 trajectories: one rank holds an empty shard and must add
+    zeros): one flat all-reduce carries every gradient and the loss; bench.py's per-rank rod slices tile the
+    global batch."""
     script = tmp_path / "w.py"
     script.write_text(_DIST_WORKER)
-    port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    port = str(29500 + (os.getpid() * 3 + world) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world), str(n_traj)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"ok {r}" in o
+
+
+def test_train_driver_shards_without_duplicates():
+    """train_knode.py hands every rank shard_range(...) as is: no rank re-trains a trajectory another rank owns
+    (round 1 gave idle ranks trajectory 0 again, which the SUM all-reduce then counted several times)."""
+    src = open(os.path.join(ROOT, "knode-cosserat_amd", "train_knode.py")).read()
+    assert "lo, hi = 0, 1" not in src
+    from krod_train import shard_range
+    for world in (3, 8):
+        owned = [t for r in range(world) for t in range(*shard_range(2, r, world))]
+        assert sorted(owned) == [0, 1]
 
 
 def test_reference_checkpoint_loads_without_reference_code(tmp_path):

@@ -134,6 +134,70 @@ def test_simulate_with_mlp(name):
     assert rel_l2(orc.simulate(D, g[f"{name}_ctl"])[:, :3, -1], g[f"{name}_traj"][:, :3, -1]) > 1e-5
 
 
+@pytest.mark.parametrize("name", ["elu512", "elu512n24"])
+def test_simulate_default_network(name):
+    """The reference's default network 28 -> 512 -> 25 inside simulate (sim_more fixture).  "elu512" carries the
+    untrained initialisation as is; the reference's own fsolve gives up (ier = 5) at its 19th solve, so the pinned
+    part ends there.  The damped Newton of the oracle - what the tests use as checker - reaches the same states."""
+    g = load_golden("sim_more")
+    D = orc.params_for(None, int(g[f"{name}_N"])).derived()
+    mlp = orc.mlp_from_arrays(g, f"mlp_{name}")
+    ier = g[f"{name}_ier"]
+    good = len(ier) - 1 if np.all(ier == 1) else int(np.argmax(ier != 1))  # solves 0..good-1 -> entries 0..good
+    assert good >= 11
+    ref = g[f"{name}_traj"][: good + 1]
+    traj = orc.simulate(D, g[f"{name}_ctl"], mlp=mlp)[: good + 1]
+    assert rel_l2(traj[:, :25], ref) < 1e-9
+    tn = orc.simulate(D, g[f"{name}_ctl"][: good + 1], mlp=mlp, solver="newton")
+    assert max(rel_l2(tn[t, :25], ref[t]) for t in range(1, good + 1)) < 1e-8
+    assert rel_l2(orc.simulate(D, g[f"{name}_ctl"][:8])[:, :3, -1], ref[:8, :3, -1]) > 1e-3  # the network matters
+
+
+def test_simulate_lbfgs_branch():
+    """knode.py:91-94 (use_fsolve=False): the oracle's restatement equals the reference's run; the root-finding
+    branch agrees with it to the accuracy L-BFGS-B reaches (2.7e-6 on the tip)."""
+    g = load_golden("sim_more")
+    D = orc.params_for(None, 10).derived()
+    ref = g["lbfgs_traj"]
+    got = orc.simulate(D, g["lbfgs_ctl"], solver="lbfgs")
+    assert rel_l2(got, ref) < 1e-9
+    root = orc.simulate(D, g["lbfgs_ctl"], solver="newton")
+    assert rel_l2(root[:, :3, -1], ref[:, :3, -1]) < 1e-5
+
+
+@pytest.mark.parametrize("P", ["0_5", "2_0", "3_0"])
+def test_n400_cfg5_inputs(P):
+    """BASELINE cfg5 inputs (N = 400, calc_controls('sine', P)): the C restatement against the reference's tips."""
+    import cosserat_oracle_c as oc
+    g = load_golden("sim_more")
+    assert np.all(g[f"n400_P{P}_ier"] == 1)
+    ctl = g[f"n400_P{P}_ctl"]
+    assert np.array_equal(ctl, np.array(orc.calc_controls("sine", float(P.replace("_", ".")), 0.05, 8)))
+    tip, tr, bad = oc.simulate(orc.params_for(None, 400), ctl)
+    ref = g[f"n400_P{P}_tip"]
+    got = np.concatenate([tr[0, :3, -1][None], tip])[: len(ref)]
+    assert bad == 0 and rel_l2(got, ref) < 1e-8
+    assert rel_l2(tr[len(ref) - 1], g[f"n400_P{P}_last"]) < 1e-7
+
+
+@pytest.mark.parametrize("use_nn", [0, 1])
+def test_torch_full_sweep(use_nn):
+    """cosserat_ode_torch.py:325-367 (fp32 torch) against the fp64 oracle sweep: value, full_rod layout
+    (column 0 = [y0; z[:, 0] of the caller], column j+1 = [y_{j+1}; z_j]) and the y it leaves behind."""
+    g = load_golden("sim_more")
+    D = orc.params_for(None, 10).derived()
+    mlp = orc.mlp_from_arrays(g, "mlp_tres") if use_nn else None
+    y0, z0, yp, zp = g["tres_y"], g["tres_z"], g["tres_yp"], g["tres_zp"]
+    yh, zh = D.c1 * y0 + D.c2 * yp, D.c1 * z0 + D.c2 * zp
+    for k, G in enumerate(g["tres_G"]):
+        y, z = y0.copy(), z0.copy()
+        r = orc.residual_euler(D, G, y, z, yh, zh, g["tres_tens"], mlp)
+        full = np.vstack([np.hstack([y[:, :1], y[:, 1:]]), np.hstack([z0[:, :1], z[:, :-1]])])
+        assert abs(np.sum(r * r) - g[f"tres_val_{use_nn}"][k]) < 2e-4 * g[f"tres_val_{use_nn}"][k]
+        assert rel_l2(full, g[f"tres_full_{use_nn}"][k]) < 1e-5
+        assert rel_l2(y, g[f"tres_yafter_{use_nn}"][k]) < 1e-5
+
+
 def test_controls_and_euler():
     g = load_golden("small")
     for key in g.files:

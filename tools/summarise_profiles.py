@@ -42,10 +42,12 @@ if fetch and write:
            "hbm_bytes_per_launch_corrected": int(2 * fk * 1024 + wk * 1024),
            "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE on gfx950 counts 1/2 of the bytes of 16-B-per-lane reads -> doubled (upper bound here: the kernel only reads its initial state and the controls); WRITE_SIZE exact for 16-B-per-lane stores; counters are in KB"}
     json.dump(hbm, open(os.path.join(P, f"{tag}_pmc_hbm.json"), "w"), indent=1)
-    print("HBM bytes/launch", hbm["hbm_bytes_per_launch_corrected"], "algorithmic", bench["roofline"]["algorithmic_bytes_per_launch"])
+    print("HBM bytes/launch", hbm["hbm_bytes_per_launch_corrected"], "algorithmic", bench["roofline"]["hbm"]["algorithmic_bytes_per_launch"])
 sq, ns = counters("sq")
 if sq:
     sq_out = {"source": "rocprofv3 --kernel-trace --pmc SQ_* (one pass), tools/collect_profiles.sh", "kernel": bench["roofline"]["kernel"],
+              "workload": f"B={bench['config']['rods_per_gpu']} N={bench['config']['N']} {bench['dtype']} Euler",
+              "steps_per_launch": bench["steps"] if bench["roofline"]["launches"] == 1 else 1,
               "per_launch": sq, "launches_profiled": ns,
               "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"}
     if sq.get("SQ_WAVE_CYCLES"):
