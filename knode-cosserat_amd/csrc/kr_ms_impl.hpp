@@ -768,6 +768,166 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
   return status;
 }
 
+// ---------------------------------------------------------------------------
+// Last resort of a time step: damped single shooting.  When the iteration above fails from the predicted AND from
+// the warm start (the reference's hybrd has a trust region where plain Newton has nothing; the untrained 512-wide
+// default network of cosserat_ode_torch.py:60-88 needs it from its 10th step on, tests/golden/sim_more.npz), the
+// wavefront solves the step the way the CPU oracle's `newton_shoot` does: Newton on the 6 base unknowns with a
+// forward-difference Jacobian from lanes 1..6 (exact - unlike the condensed one it also sees the MLP's dependence
+// on p), every update taken as G - lam d with lam halved until the residual norm has decreased.  Lane 0 streams
+// every sweep; the sweep whose full Newton update is below the tolerance is the accepted one.  58 lanes idle along
+// the N - 1 dependent grid points: this path is for robustness, not speed.  Leaves L.Xs consistent with the result.
+// ---------------------------------------------------------------------------
+template <typename T, bool DIAG, int SCHEME, int HS, bool PERSIST, bool NN>
+__device__ __forceinline__ int ss_newton_damped(const RodConst<T>& Pc, const MlpDev<T>& M, const MsLds<T>& L,
+                                                const MsRole& R, int lane, const SweepCtx<T, HS>& C, MsSolveArgs<T>& S,
+                                                int& it) {
+  const int N = Pc.N;
+  const int col = lane < 7 ? lane : 0;  // lanes 7.. duplicate the unperturbed column and store nothing
+  T G[6], Gold[6], d[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { G[k] = L.Xs[0 * MS_YP + 7 + k]; Gold[k] = G[k]; d[k] = T(0); }
+  T nr_old = T(-1), lam = T(1);
+  bool have_trial = false;
+  int status = KR_ST_MAXIT;
+  const int maxit = 8 * S.maxit;
+  it = 0;
+  T* Rx = L.Tm;  // [7][6] residuals of the seven columns
+  while (true) {
+    T hs[6];
+    RodState<T> y;
+    {
+      const T* cold = L.cold;
+      y.p = {cold[CD_P0], cold[CD_P0 + 1], cold[CD_P0 + 2]};
+      y.h0 = cold[CD_H0]; y.h1 = cold[CD_H0 + 1]; y.h2 = cold[CD_H0 + 2]; y.h3 = cold[CD_H0 + 3];
+      y.q = {cold[CD_Q0], cold[CD_Q0 + 1], cold[CD_Q0 + 2]};
+      y.w = {cold[CD_W0], cold[CD_W0 + 1], cold[CD_W0 + 2]};
+      T Gl[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        hs[k] = S.fd_eps * fmax(fabs(G[k]), T(1));
+        Gl[k] = G[k] + (col == k + 1 ? hs[k] : T(0));
+      }
+      y.n = {Gl[0], Gl[1], Gl[2]};
+      y.m = {Gl[3], Gl[4], Gl[5]};
+    }
+    T hv[HS];
+    load_hist_vec<T, HS>(C.hbase, hv);
+    int gnext = 1, jnext = ms_interval_start(1, R.sbase, R.srem);  // interval starts passed on the way (for L.Xs)
+    for (int j = 0; j < N - 1; ++j) {
+      RodState<T> k1;
+      V3<T> v, u;
+      eval_point<T, DIAG, NN, HS>(Pc, M, C, y, hv, k1, v, u);
+      if (lane == 0) {
+        T rec[KR_SLOTS];
+        record_from(y, v, u, rec);
+        if (S.out_rod) store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
+        if constexpr (PERSIST) {
+          T lead[12];
+#pragma unroll
+          for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+          store_vec<T, 12>(L.c12 + (size_t)j * 12, lead);
+        }
+        if (j == jnext && gnext < MS_P) {
+          T yr[19];
+          state_to_rows(y, yr);
+#pragma unroll
+          for (int q = 0; q < 19; ++q) L.Xs[gnext * MS_YP + q] = yr[q];
+        }
+      }
+      if (j == jnext && gnext < MS_P) { ++gnext; jnext = ms_interval_start(gnext, R.sbase, R.srem); }
+      if constexpr (SCHEME == KR_EULER) {
+        load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hv);
+        y = state_axpy(y, Pc.ds, k1);
+      } else {
+        T hn[HS], hm[HS];
+        load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hn);
+#pragma unroll
+        for (int c = 0; c < HS; ++c) hm[c] = T(0.5) * (hv[c] + hn[c]);
+        RodState<T> k2, k3, k4;
+        V3<T> v2, u2;
+        RodState<T> ya = state_axpy(y, Pc.ds * T(0.5), k1);
+        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k2, v2, u2);
+        ya = state_axpy(y, Pc.ds * T(0.5), k2);
+        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k3, v2, u2);
+        ya = state_axpy(y, Pc.ds, k3);
+        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hn, k4, v2, u2);
+        RodState<T> ksum = state_axpy(k1, T(2), k2);
+        ksum = state_axpy(ksum, T(2), k3);
+        ksum = state_axpy(ksum, T(1), k4);
+        y = state_axpy(y, Pc.ds / T(6), ksum);
+#pragma unroll
+        for (int c = 0; c < HS; ++c) hv[c] = hn[c];
+      }
+    }
+    if (lane == 0) {
+      T rec[KR_SLOTS];
+      record_from(y, S.vlast, S.ulast, rec);
+      if (S.out_rod) store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+      if constexpr (PERSIST) {
+        T lead[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+        store_vec<T, 12>(L.c12 + (size_t)(N - 1) * 12, lead);
+      }
+      if (S.tip) { S.tip[0] = y.p.x; S.tip[1] = y.p.y; S.tip[2] = y.p.z; }
+    }
+    ++it;
+    if (lane < 7) {
+      Rx[lane * 6 + 0] = L.cold[CD_FTIP + 0] - y.n.x; Rx[lane * 6 + 1] = L.cold[CD_FTIP + 1] - y.n.y;
+      Rx[lane * 6 + 2] = L.cold[CD_FTIP + 2] - y.n.z; Rx[lane * 6 + 3] = L.cold[CD_MTIP + 0] - y.m.x;
+      Rx[lane * 6 + 4] = L.cold[CD_MTIP + 1] - y.m.y; Rx[lane * 6 + 5] = L.cold[CD_MTIP + 2] - y.m.z;
+    }
+    wave_sync();
+    T a[6][7];
+    T nr = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      a[k][6] = Rx[k];
+      nr = fma(a[k][6], a[k][6], nr);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const T ih = fast_rcp(hs[c]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a[k][c] = (Rx[(c + 1) * 6 + k] - a[k][6]) * ih;
+    }
+    wave_sync();
+    // backtracking (nr is a squared norm; a NaN fails the comparison and counts as "not decreased")
+    const T keep = T(1) - T(1e-4) * lam;
+    if (have_trial && !(nr <= nr_old * keep * keep) && lam > T(1.0 / 1024.0) && it < maxit) {
+      lam *= T(0.5);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) G[k] = Gold[k] - lam * d[k];
+      continue;
+    }
+    T dn[6];
+    solve6(a, dn);
+    T dmax = T(0), gmax = T(1);
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      dmax = fmax(dmax, fabs(dn[k]));
+      gmax = fmax(gmax, fabs(G[k]));
+      finite = finite && isfinite(dn[k]);
+    }
+    if (!finite) { status = KR_ST_NONFINITE; break; }
+    if (dmax <= S.tol * gmax) { status = KR_ST_CONVERGED; break; }  // this sweep's state is the accepted one
+    if (it >= maxit) break;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { Gold[k] = G[k]; d[k] = dn[k]; G[k] = G[k] - dn[k]; }
+    nr_old = nr;
+    lam = T(1);
+    have_trial = true;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.Xs[0 * MS_YP + 7 + k] = G[k];
+  }
+  wave_sync();
+  return status;
+}
+
 template <typename T, int HS>
 __device__ __forceinline__ void ms_ctx_init(const T* cold, const T* hist, const T* tens4, SweepCtx<T, HS>& C) {
   C.hbase = hist;
@@ -1079,6 +1239,13 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
     }
+    if (status != KR_ST_CONVERGED) {  // plain Newton failed from the warm start too: damped single shooting from there
+      ms_pred_guess<T>(Q, 0, lane, L.cold, L.Xs);
+      wave_sync();
+      if (lane < 6) L.Xs[0 * MS_YP + 7 + lane] = A.G[rod * 6 + lane];
+      wave_sync();
+      status = ss_newton_damped<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it);
+    }
     ms_pred_update<T>(Q, order, status, A.pred_limit, lane, L.Xs, stamps);
     Q.kappa = S.kappa;
     ms_pred_save<T>(Q, img, lane);
@@ -1098,6 +1265,11 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
     }
     wave_sync();
     status = ms_newton<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it, stamps);
+    if (status != KR_ST_CONVERGED) {  // damped single shooting from the caller's guess
+      if (lane < 6) L.Xs[0 * MS_YP + 7 + lane] = A.G[rod * 6 + lane];
+      wave_sync();
+      status = ss_newton_damped<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it);
+    }
   }
   if (lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * MS_YP + 7 + lane];
   if (lane == 0) {
@@ -1215,6 +1387,11 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
       stamps.retries += 1;
       KR_STAMP(tp);
 #endif
+    }
+    if (status != KR_ST_CONVERGED) {  // plain Newton failed from the warm start too: damped single shooting from there
+      if (lane < 6) L.Xs[0 * MS_YP + 7 + lane] = Gguess;
+      wave_sync();
+      status = ss_newton_damped<T, DIAG, SCHEME, HS, true, NN>(Pc, M, L, R, lane, C, S, it);
     }
     if (lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
     ms_pred_update<T>(Q, order, status, A.predictor, lane, L.Xs, stamps);

@@ -364,9 +364,9 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
   }
 
   // ---- per-rod inputs ------------------------------------------------------
-  T G[6];
+  T G[6], G0[6];  // G0: the caller's guess (knode.py:89 warm start), where the damped second phase starts over
 #pragma unroll
-  for (int k = 0; k < 6; ++k) G[k] = A.G[rod * 6 + k];
+  for (int k = 0; k < 6; ++k) G0[k] = G[k] = A.G[rod * 6 + k];
   if (A.pred_order > 0) {
     // G of earlier steps = n, m at the base of the stored states; extrapolate in time
     const size_t o0 = rod * rod_elems + SL_N;
@@ -402,6 +402,15 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
   int status = KR_ST_MAXIT;
   int it = 0;
   T dn_prev = T(-1);
+  // Second phase for rods the plain iteration did not solve (the reference's hybrd has a trust region): restart
+  // from the caller's guess with backtracking - every update is taken as G - lam d, lam halved until the residual
+  // norm has decreased (what the CPU oracle's newton_shoot does).  Same root, same stopping rule.
+  bool damped = false, have_trial = false;
+  int maxit = A.maxit;
+  T Gold[6], dsv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { Gold[k] = G[k]; dsv[k] = T(0); }
+  T nr_old = T(-1), lam = T(1);
 
   while (true) {
     // ---- one spatial sweep, all 64 lanes ----------------------------------
@@ -492,6 +501,9 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
 #pragma unroll
       for (int k = 0; k < 6; ++k) a[k][c] = (__shfl(res[k], gbase + c + 1, WAVE) - a[k][6]) * ih;
     }
+    T nr = T(0);  // squared residual norm at the point just swept (a NaN fails the comparison below)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) nr = fma(a[k][6], a[k][6], nr);
     T d[6];
     solve6(a, d);
     T dn = T(0), gn = T(1);
@@ -503,7 +515,13 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
       finite = finite && isfinite(d[k]);
     }
     if (!done) {
-      if (!finite) {
+      const T keep = T(1) - T(1e-4) * lam;
+      if (damped && have_trial && !(nr <= nr_old * keep * keep) && lam > T(1.0 / 1024.0) && it < maxit) {
+        lam *= T(0.5);  // rejected trial point: shorter step along the same direction
+#pragma unroll
+        for (int k = 0; k < 6; ++k) G[k] = Gold[k] - lam * dsv[k];
+        stored = false;
+      } else if (!finite) {
         done = true;
         status = KR_ST_NONFINITE;
       } else if (storing && dn <= A.tol * gn) {
@@ -511,17 +529,33 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
         status = KR_ST_CONVERGED;
       } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) G[k] -= d[k];
+        for (int k = 0; k < 6; ++k) { Gold[k] = G[k]; dsv[k] = d[k]; G[k] -= d[k]; }
+        nr_old = nr;
+        lam = T(1);
+        have_trial = damped;
         if (predict_final<T>(dn / gn, dn_prev, A.tol, A.tolA)) storing = true;
         dn_prev = dn / gn;
         stored = false;
-        if (it >= A.maxit) {
+        if (it >= maxit) {
           done = true;
           status = KR_ST_MAXIT;
         }
       }
     }
     if (__all(done)) {
+      if (!damped && __any(valid && status != KR_ST_CONVERGED)) {
+        damped = true;  // wave-uniform; only the rods that failed start over
+        if (status != KR_ST_CONVERGED) {
+          done = false; stored = false; storing = true; have_trial = false;
+          status = KR_ST_MAXIT;
+          it = 0;
+          maxit = 8 * A.maxit;
+          dn_prev = T(-1);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) G[k] = G0[k];
+        }
+        continue;
+      }
       // rods that stopped without a stored sweep (iteration cap / non-finite):
       // one more pass so that state_next is always the sweep of the returned G
       if (__any(!stored)) flush = true;
