@@ -180,38 +180,49 @@ def main():
     tip = torch.empty((B, K, 3), dtype=tdt, device=dev)
     tip_pre = torch.empty((B, max(pre, 1), 3), dtype=tdt, device=dev)
 
-    def run_cold(T, ramp_only=False):
+    # a second handle (own predictor image, own options) for everything that is not the measured trajectory
+    robot2 = CosseratRod(use_fsolve=True, device=dev_index)
+    setup_robot(robot2)
+    robot2.N = N
+    robot2.compute_intermediate_terms()
+    h2 = robot2._native()
+
+    def run_cold(T, dt=None):
         """T steps from the straight rod with no predictor hand-over: (seconds, unconverged rod-steps)."""
-        c = torch.as_tensor(rank_controls(B, world, rank, T, robot.del_t), device=dev).to(tdt).contiguous()
-        st = h.new_state(B, tdt, n_slots=3)
-        g0 = torch.zeros((B, 6), dtype=tdt, device=dev)
+        dt = dt or tdt
+        c = torch.as_tensor(rank_controls(B, world, rank, T, robot.del_t), device=dev).to(dt).contiguous()
+        st = h2.new_state(B, dt, n_slots=3)
+        g0 = torch.zeros((B, 6), dtype=dt, device=dev)
         stat = torch.zeros((B, T), dtype=torch.int32, device=dev)
-        h.init_straight(st[0])
+        h2.init_straight(st[0])
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        h.simulate(c, st, g0, ring=True, status=stat)
+        h2.simulate(c, st, g0, ring=True, status=stat)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3, int((stat != 0).sum())
 
-    # clock ramp, not part of the untimed steps: an idle MI355X needs a few hundred ms of load before its shader
-    # clock settles; the same solver runs on scratch copies of the problem until then.  (Ramp and untimed steps go
-    # through the one-launch-per-step form of the same solver, so that the persistent kernel appears in a
-    # rocprofv3 trace of `bench.py --no-cpu` exactly once: the timed K steps.)
+    # Clock ramp, not part of the untimed steps: an idle MI355X needs a few hundred ms of full load before its
+    # shader clock settles, and drops it again within milliseconds of light load.  The ramp runs the persistent
+    # solver in the OTHER precision on scratch copies of the problem (a different kernel instantiation, so that in a
+    # rocprofv3 trace of `bench.py --no-cpu` the timed kernel appears exactly once: the K timed steps); the untimed
+    # steps of the trajectory go through the one-launch-per-step form for the same reason.
+    ramp_dt = torch.float32 if args.dtype == "f64" else torch.float64
     h.set_option("keep_predictor", 0)
     persistent_default = h.get_option("persistent")
-    h.set_option("persistent", 0)
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.5:
-        run_cold(30)
-    h.set_option("persistent", persistent_default)
 
+    def ramp(seconds):
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < seconds:
+            run_cold(200, ramp_dt)
+
+    ramp(0.5)
     cold = None
     if not args.no_cpu:
         cold = {}
         for T in (64, 200):
-            secs, bad = min(run_cold(T) for _ in range(2))
+            secs, bad = min(run_cold(T) for _ in range(3))
             cold[f"T{T}"] = {"value": round(B * T / secs, 1), "ms_per_step": round(secs / T * 1e3, 4), "unconverged": bad}
 
     # the untimed and the timed steps are one trajectory advanced by two calls: the second call resumes the
@@ -229,6 +240,7 @@ def main():
         h.init_straight(states[0])
         prev_init = None
     h.set_option("persistent", persistent_default)
+    ramp(0.25)  # (on the second handle: the predictor image the untimed steps left on `h` is not touched)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -322,7 +334,7 @@ def main():
         if cold is not None:
             out["cold_start"] = {"unit": "rod-steps/s", **cold,
                                  "note": "T steps from the straight rod in one call, no warm-up, no predictor hand-over "
-                                         "(SURVEY 8d cfg3: T=64, cfg2: T=200), best of 2"}
+                                         "(SURVEY 8d cfg3: T=64, cfg2: T=200), best of 3"}
         if world == 1 and not args.no_cpu:
             Tc = min(pre + K, max(50, pre + 20))
             cb, tips = cpu_baseline(N, robot.del_t, B, Tc)
