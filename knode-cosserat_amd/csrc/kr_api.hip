@@ -563,9 +563,61 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
       md.wfrag[k] = static_cast<double*>(pwd); md.bfrag[k] = static_cast<double*>(pbd);
       mf.ksteps[k] = md.ksteps[k] = ks;
       mf.otiles[k] = md.otiles[k] = tiles;
+      {
+        // base chain of mlp_jvp.hpp: fp32 A fragments of v_mfma_f64_4x4x4_4b, four k-steps per 16-byte element
+        const int kg = k == 0 ? 2 : prev_tiles;  // k-groups of 16 inputs (first layer: 28 -> 32)
+        std::vector<float> wq((size_t)tiles * kg * 64 * 4, 0.f), bq((size_t)tiles * 64, 0.f);
+        for (int t = 0; t < tiles; ++t)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int uo = 16 * t + (lane & 15);
+            for (int g = 0; g < kg; ++g)
+              for (int e = 0; e < 4; ++e) {
+                const int ui = 4 * (4 * g + e) + (lane >> 4);
+                if (uo < out && ui < in) wq[(((size_t)t * kg + g) * 64 + lane) * 4 + e] = hw[(size_t)uo * in + ui];
+              }
+            const int ub = 16 * t + 4 * ((lane >> 2) & 3) + (lane >> 4);  // unit of this lane in the D layout
+            if (ub < out) bq[(size_t)t * 64 + lane] = hb[ub];
+          }
+        void *pw, *pb;
+        KR_HIP(hipMalloc(&pw, wq.size() * sizeof(float))); h->mlp_allocs.push_back(pw);
+        KR_HIP(hipMalloc(&pb, bq.size() * sizeof(float))); h->mlp_allocs.push_back(pb);
+        KR_HIP(hipMemcpy(pw, wq.data(), wq.size() * sizeof(float), hipMemcpyHostToDevice));
+        KR_HIP(hipMemcpy(pb, bq.data(), bq.size() * sizeof(float), hipMemcpyHostToDevice));
+        mf.wq[k] = md.wq[k] = static_cast<float*>(pw);
+        mf.bq[k] = md.bq[k] = static_cast<float*>(pb);
+        mf.kgroups[k] = md.kgroups[k] = kg;
+      }
+      {
+        // bf16 fragments of the JVP chain (mlp_jvp.hpp): k-steps of 32; beyond the first layer the k order is the one
+        // two adjacent 16x16x32 accumulator tiles present: slot (q, j) of k-step s = unit 32 s + 4 q + j (j < 4),
+        // 32 s + 16 + 4 q + j - 4 (j >= 4)
+        const int jks = k == 0 ? 1 : prev_tiles / 2;
+        std::vector<uint16_t> jf((size_t)tiles * jks * 64 * 8);
+        auto bf16 = [](float f) {
+          uint32_t u;
+          std::memcpy(&u, &f, 4);
+          return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        };
+        for (int t = 0; t < tiles; ++t)
+          for (int s2 = 0; s2 < jks; ++s2)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int uo = 16 * t + (lane & 15), q = lane >> 4;
+              for (int j = 0; j < 8; ++j) {
+                const int ui = k == 0 ? 8 * q + j : 32 * s2 + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
+                const float w = (uo < out && ui < in) ? hw[(size_t)uo * in + ui] : 0.f;
+                jf[(((size_t)t * jks + s2) * 64 + lane) * 8 + j] = bf16(w);
+              }
+            }
+        void* pj;
+        KR_HIP(hipMalloc(&pj, jf.size() * sizeof(uint16_t)));  h->mlp_allocs.push_back(pj);
+        KR_HIP(hipMemcpy(pj, jf.data(), jf.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        mf.jfrag[k] = md.jfrag[k] = pj;
+        mf.jksteps[k] = md.jksteps[k] = jks;
+      }
       prev_tiles = tiles;
     }
     mf.mfma_ok = md.mfma_ok = h->mfma_mlp ? 1 : 0;
+    mf.jvp_ok = md.jvp_ok = (n_layers == 2 || dims[2] <= 64 * 3) ? 1 : 0;  // MJ_ACT_SLOTS - 1 chunks of the second hidden layer
   }
   h->mlp_f = mf;
   h->mlp_d = md;

@@ -38,6 +38,16 @@ struct MlpDev {
   int ksteps[KR_MAX_LAYERS];   // k-steps (of 4 inputs) per output tile
   int otiles[KR_MAX_LAYERS];   // 16-unit output tiles (hidden layers: a multiple of 4)
   int mfma_ok;                 // the network has a shape the matrix-core evaluator supports
+  // Jacobian-vector-product chain of the multiple-shooting sweeps (mlp_jvp.hpp): bf16 A fragments
+  // [tile][k-step of 32][lane][8], shared by both precisions
+  const void* jfrag[KR_MAX_LAYERS];
+  int jksteps[KR_MAX_LAYERS];
+  // base chain of the same evaluator (v_mfma_f64_4x4x4_4b for both precisions): fp32 A fragments
+  // [tile][k-group of 16 inputs][lane][4 k-steps], biases [tile][lane] in that instruction's D layout
+  const float* wq[KR_MAX_LAYERS];
+  const float* bq[KR_MAX_LAYERS];
+  int kgroups[KR_MAX_LAYERS];
+  int jvp_ok;                  // shape served by mlp_jvp.hpp (second hidden layer <= 64 (MJ_ACT_SLOTS - 1) units)
 };
 
 }  // namespace kr

@@ -154,7 +154,7 @@ __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = fa
   // XB, Tm, Es are contiguous; with the MLP on the same region doubles as the 64 x 32 exchange
   // tile of mlp_mfma.hpp.  The cold table sits in front of XB so the tile cannot clobber it.
   size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);
-  if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
+  if (nn && alg < mj_scratch_elems<T>()) alg = mj_scratch_elems<T>();  // scratch of the base + JVP evaluator
   alg = (alg + 3) & ~size_t(3);
   size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + 40 + alg;  // 40: Ti (6 x 6 inverse)
   if (persist) n += (size_t)N * 12;
@@ -286,7 +286,7 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist, bool 
   L.Tm = L.XB + 2 * MS_YP * 8;
   L.Es = L.Tm + 48;
   size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);  // as in ms_lds_elems
-  if (nn && alg < (size_t)WAVE * MM_TILE_LD) alg = (size_t)WAVE * MM_TILE_LD;
+  if (nn && alg < mj_scratch_elems<T>()) alg = mj_scratch_elems<T>();
   L.c12 = persist ? L.XB + ((alg + 3) & ~size_t(3)) : nullptr;
   return L;
 }
@@ -1208,6 +1208,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
     // condensation buffers (XB .. Es), which are used between sweeps only
     C.tile = L.XB;
     C.lane = lane;
+    C.role.iv = R.iv; C.role.col = R.col; C.role.idle = R.idle; C.role.jvp = true;
   }
   MsSolveArgs<T> S;
   {  // z of the last grid point is never touched by a sweep
@@ -1361,6 +1362,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
     if constexpr (NN) {  // exchange tile of the matrix-core MLP, on top of the condensation buffers
       C.tile = L.XB;
       C.lane = lane;
+      C.role.iv = R.iv; C.role.col = R.col; C.role.idle = R.idle; C.role.jvp = true;
     }
     if (t + 1 < A.T_steps) {  // next step's tensions: issued now, consumed after this step's solve
 #pragma unroll

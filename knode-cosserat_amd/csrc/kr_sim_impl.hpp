@@ -24,6 +24,7 @@
 #include "kr_internal.hpp"
 #include "mlp_lane.hpp"
 #include "mlp_mfma.hpp"
+#include "mlp_jvp.hpp"
 
 namespace kr {
 
@@ -227,10 +228,15 @@ __device__ __forceinline__ void solve6(T (&a)[6][7], T (&x)[6]) {
 // ---------------------------------------------------------------------------
 // MLP correction inside a sweep (cosserat_ode.py:169-184)
 // ---------------------------------------------------------------------------
+// role of a lane in a multiple-shooting sweep, for the base + JVP evaluator (mlp_jvp.hpp); jvp = false elsewhere
+struct NnRole {
+  int iv = 0, col = 0;
+  bool idle = false, jvp = false;
+};
 template <typename T, int HS>
 __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB, int stride, T* tile, int lane,
-                                           const RodState<T>& y, const T (&hv)[HS], V3<T> tf, RodState<T>& ys, V3<T>& v,
-                                           V3<T>& u) {
+                                           const NnRole& role, const RodState<T>& y, const T (&hv)[HS], V3<T> tf,
+                                           RodState<T>& ys, V3<T>& v, V3<T>& u) {
   T yr[19];
   state_to_rows(y, yr);
   if constexpr (HS != HS_NNH) {
@@ -241,7 +247,8 @@ __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB,
       x[19] = v.x; x[20] = v.y; x[21] = v.z; x[22] = u.x; x[23] = u.y; x[24] = u.z;
       x[25] = tf.x; x[26] = tf.y; x[27] = tf.z;
       T d[25];
-      mlp_mfma_eval<T>(M, x, tile, lane, d);
+      if (role.jvp && M.jvp_ok) mlp_jvp_eval<T>(M, x, tile, lane, role.iv, role.col, role.idle, d);  // wave-uniform choice
+      else mlp_mfma_eval<T>(M, x, tile, lane, d);
       T yr2[19];
       state_to_rows(ys, yr2);
 #pragma unroll
@@ -297,6 +304,7 @@ struct SweepCtx {
   int astride;
   T* tile;          // LDS exchange tile of the wave (matrix-core evaluator)
   int lane;
+  NnRole role;
   V3<T> tf, fconst;
 };
 
@@ -306,7 +314,7 @@ __device__ __forceinline__ void eval_point(const RodConst<T>& P, const MlpDev<T>
                                            const RodState<T>& y, const T (&hv)[HS], RodState<T>& k, V3<T>& v,
                                            V3<T>& u) {
   ode_eval<T, DIAG>(P, y, hist_from<T, HS>(hv), C.fconst, k, v, u);
-  if constexpr (NN) nn_correct<T, HS>(M, C.bufA, C.bufB, C.astride, C.tile, C.lane, y, hv, C.tf, k, v, u);
+  if constexpr (NN) nn_correct<T, HS>(M, C.bufA, C.bufB, C.astride, C.tile, C.lane, C.role, y, hv, C.tf, k, v, u);
 }
 
 template <typename T, bool DIAG, int SCHEME, bool HIST_LDS, bool NN, int HS>

@@ -1,0 +1,447 @@
+// mlp_jvp.hpp - the residual MLP inside a multiple-shooting sweep: one exact evaluation per sub-interval,
+// Jacobian-vector products for the forward-difference columns.
+//
+// In a sweep of the multiple-shooting kernels (kr_ms_impl.hpp) the 58 active lanes of a rod's wavefront are
+// 4 unperturbed trajectories (one per sub-interval) and 54 trajectories that differ from "their" unperturbed one
+// by a forward-difference perturbation of relative size 1e-7 (fp64) / 1e-3 (fp32).  Evaluating the network
+// (reference cosserat_ode.py:90-112, 169-184) in full precision for all 64 lanes - what mlp_mfma.hpp does and what
+// single shooting still uses - spends 93 % of the matrix-core time on inputs that are equal to 7 digits.  Here:
+//
+//   * BASE: the 4 unperturbed inputs go through the network in the arithmetic type of the sweep (fp64 in
+//     `simulate`, like the reference) on v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, as ONE tile of 16 sample
+//     columns (4 used).  These outputs are what the stored trajectory and the Newton residual are made of.
+//   * JVP: for a perturbed lane  NN(x_b + dx) = NN(x_b) + J(x_b) dx + O(dx^2)  with  J dx = W_L diag(act'_{L-1}) ...
+//     diag(act'_1) W_1 dx  evaluated on v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulation): 16 perturbed
+//     lanes of sub-interval i are exactly one 16-column sample tile, whose act' factors - those of the interval's
+//     base point - depend on the accumulator ROW only, so they are applied in registers.  The truncation O(dx^2) is
+//     what the forward difference itself commits; the bf16 rounding (2^-9 relative) only touches the Jacobian of
+//     the Newton iteration, never the residual, so the root is unchanged and the contraction stays ~1e-3 per sweep
+//     better than any stopping tolerance needs.  Newton also no longer differentiates across activation kinks:
+//     act' is the base point's one-sided derivative (FD through an ELU/ReLU kink mixes both sides).
+//
+// Register chaining: a D tile of 16x16x32 (lane l: column l&15, rows 4(l>>4)+r) holds, for two adjacent unit tiles,
+// the eight k-values a lane needs as B operand of the next layer (k-slot (q, j) of k-step s = unit 32s + 4q + j for
+// j < 4, 32s + 16 + 4q + j - 4 otherwise); the host packs the next layer's bf16 weights in that k order, so no LDS
+// transpose is needed between layers.  The base chain keeps the layouts of mlp_mfma.hpp.
+#pragma once
+#include "mlp_mfma.hpp"
+
+namespace kr {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+struct MjVec;  // 16-byte vector of T
+template <>
+struct MjVec<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int n = 4; };
+template <>
+struct MjVec<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int n = 2; };
+
+constexpr int MJ_XB_LD = 28;                 // pitch of the base input / output rows [4][28] (T): 16-byte aligned rows
+constexpr int MJ_ACT_SLOTS = 4;              // act' tables the scratch holds (one per 64-unit hidden chunk of a 3-layer net)
+constexpr int MJ_ACTP_BYTES = MJ_ACT_SLOTS * 4 * 64 * 4;  // each [4 intervals][64 units] f32
+constexpr int MJ_DX_LD = 32;                 // bf16 per perturbed sample row
+constexpr int MJ_DOUT_LD = 28;               // f32 per output row: 16-byte aligned rows, 25 used
+template <typename T>
+__host__ __device__ constexpr size_t mj_xb_bytes() { return (size_t)4 * MJ_XB_LD * sizeof(T); }  // 896 / 448: multiples of 16
+template <typename T>
+__host__ __device__ constexpr size_t mj_scratch_bytes() {
+  return mj_xb_bytes<T>() + MJ_ACTP_BYTES + (size_t)64 * MJ_DOUT_LD * 4;  // (dx [64][32] bf16 aliases dout)
+}
+template <typename T>
+__host__ __device__ constexpr size_t mj_scratch_elems() { return (mj_scratch_bytes<T>() + sizeof(T) - 1) / sizeof(T); }
+
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {  // v_cvt_pk_bf16_f32: round to nearest even
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+
+// d act / d pre from the ACTIVATED value a (what the base chain holds in its accumulators)
+template <int ACT>
+__device__ __forceinline__ float act_grad_from_value(float a) {
+  if constexpr (ACT == KR_ACT_ELU) return a > 0.f ? 1.f : a + 1.f;          // e^x = elu(x) + 1 for x <= 0
+  else if constexpr (ACT == KR_ACT_TANH) return 1.f - a * a;
+  else if constexpr (ACT == KR_ACT_SOFTPLUS) return 1.f - __expf(-a);       // sigmoid(x) = 1 - e^{-softplus(x)}
+  else if constexpr (ACT == KR_ACT_RELU) return a > 0.f ? 1.f : 0.f;
+  else return 1.f;
+}
+
+// what the evaluator needs of MlpDev (scalar registers)
+struct JvpNet {
+  const float* wq[3];       // base chain: A fragments of v_mfma_f64_4x4x4_4b, fp32 (the weights ARE fp32 numbers), 4 k-steps per
+  const float* bq[3];       //   16-byte element: [tile][k-group][lane][4]; biases [tile][lane] in the D layout
+  const bf16x8* j[3];       // JVP chain: bf16 A fragments [tile][k-step of 32][lane]
+  int kg[3], ot[3], jks[3]; // k-groups (of 16 inputs) per tile, 16-unit tiles, JVP k-steps
+  int L;
+};
+template <typename T>
+__device__ __forceinline__ JvpNet jvp_net(const MlpDev<T>& M) {
+  JvpNet n;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    n.wq[k] = M.wq[k]; n.bq[k] = M.bq[k]; n.j[k] = reinterpret_cast<const bf16x8*>(M.jfrag[k]);
+    n.kg[k] = M.kgroups[k]; n.ot[k] = M.otiles[k]; n.jks[k] = M.jksteps[k];
+  }
+  n.L = M.n_layers;
+  return n;
+}
+
+#define MJ_LDS __attribute__((address_space(3)))
+#define MJ_GLB __attribute__((address_space(1)))
+typedef MJ_GLB const float* gfp;
+typedef MJ_GLB const f32x4* gf4p;
+typedef MJ_GLB const bf16x8* gbfp;
+
+// v_mfma_f64_4x4x4_4b_f64 (measured layout, tools/ubench_mfma2.hip): 4 independent 4x4x4 products; lane l holds
+//   A_b[i][k]:  k = l >> 4, b = (l >> 2) & 3, i = l & 3        B_b[k][j]:  k = l >> 4, b = (l >> 2) & 3, j = l & 3
+//   D_b[i][j]:  i = l >> 4, b = (l >> 2) & 3, j = l & 3
+// Used as out^T[16 units x 4 samples] += W[16 x 4] in^T[4 x 4]: block b carries units 4 b .. 4 b + 3 of the tile,
+// every block the same inputs; 17 cycles per instruction against 64 for the 16x16x4 form, whose other 12 sample
+// columns would be padding here.  The result (unit 16 t + 4 b + i on lane (i, b, j)) becomes the next layer's B
+// operand (input 4 s + k on lane (k, *, j)) by a ds_swizzle that copies block s & 3 of accumulator s >> 2 to all blocks.
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+template <int BSRC>
+__device__ __forceinline__ double bcast_block(double v) {
+  constexpr int pat = 0x13 | ((BSRC << 2) << 5);  // bit-mask mode: lane' = (lane & 0b10011) | (BSRC << 2)
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_swizzle((int)(bits & 0xFFFFFFFFll), pat);
+  const int hi = __builtin_amdgcn_ds_swizzle((int)(bits >> 32), pat);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// acc[o] += W(tile0 + o, k-steps 4 kg0 .. 4 kg0 + 4 NKG) * b(ks) for NO tiles; w4: fragments requested earlier
+template <int NO, int NKG, typename BFn>
+__device__ __forceinline__ void base_run(double (&acc)[NO], const f32x4 (&w4)[NKG][NO], BFn bsrc) {
+#pragma unroll
+  for (int g = 0; g < NKG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double bv = bsrc(4 * g + e);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) acc[o] = mfma4((double)w4[g][o][e], bv, acc[o]);
+    }
+}
+template <int NO, int NKG>
+__device__ __forceinline__ void base_load(f32x4 (&w4)[NKG][NO], gf4p w, int kgroups, int tile0, int kg0, int lane) {
+#pragma unroll
+  for (int g = 0; g < NKG; ++g)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) w4[g][o] = w[((size_t)(tile0 + o) * kgroups + kg0 + g) * 64 + lane];
+}
+// B operand of k-step ks (0..15) from the four accumulators of a 64-unit chunk
+__device__ __forceinline__ double chunk_operand(const double (&h)[4], int ks) {
+  const double v = h[ks >> 2];
+  switch (ks & 3) {
+    case 0: return bcast_block<0>(v);
+    case 1: return bcast_block<1>(v);
+    case 2: return bcast_block<2>(v);
+    default: return bcast_block<3>(v);
+  }
+}
+// activation of a chunk (4 values per lane, all of them real) and its act' to the table [interval j][unit]
+template <int ACT>
+__device__ __forceinline__ void chunk_activate(double (&h)[4], MJ_LDS float* actp, int lane) {
+  activate_block<double, ACT, 4>(h);
+  const int unit0 = 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) actp[(lane & 3) * 64 + 16 * o + unit0] = act_grad_from_value<ACT>((float)h[o]);
+}
+
+// JVP: dst[o][s] += A(o, ks) * b[s][ks]  over KS k-steps of 32, NO unit tiles, 4 sample tiles
+template <int NO, int KS>
+__device__ __forceinline__ void jvp_load(bf16x8 (&a)[KS][NO], gbfp w, int ksteps, int tile0, int ks0, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) a[ks][o] = w[((size_t)(tile0 + o) * ksteps + ks0 + ks) * 64 + lane];
+}
+template <int NO, int KS>
+__device__ __forceinline__ void jvp_accumulate(f32x4 (&dst)[NO][4], const bf16x8 (&a)[KS][NO], const bf16x8 (&b)[4][KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dst[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][o], b[s][ks], dst[o][s], 0, 0, 0);
+}
+// D tiles of a 64-unit hidden chunk (4 unit tiles x 4 sample tiles) -> scaled by act' of the tile's interval ->
+// bf16 B operands of the next layer (2 k-steps of 32 units)
+__device__ __forceinline__ void jvp_scale_pack(const f32x4 (&dh)[4][4], const MJ_LDS float* actp, int lane, bf16x8 (&b)[4][2]) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f32x4 g[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) g[o] = *reinterpret_cast<const MJ_LDS f32x4*>(actp + s * 64 + 16 * o + 4 * q);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 p;
+      const f32x4 lo = dh[2 * ks][s] * g[2 * ks], hi = dh[2 * ks + 1][s] * g[2 * ks + 1];
+      p[0] = pack_bf2(lo[0], lo[1]); p[1] = pack_bf2(lo[2], lo[3]);
+      p[2] = pack_bf2(hi[0], hi[1]); p[3] = pack_bf2(hi[2], hi[3]);
+      b[s][ks] = __builtin_bit_cast(bf16x8, p);
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Base + JVP evaluation for one wavefront on the LDS scratch:
+//   xb   [4][MJ_XB_LD] T       in: row i = input of the base lane of interval i;  out: its 25 outputs
+//   actp [slots][4][64] f32    scratch: act' of the hidden chunks at the 4 base points
+//   dx   [64][32] bf16         in: row 16 i + c = dx of perturbed column c of interval i (unused rows zero)
+//   dout [64][MJ_DOUT_LD] f32  out: J dx of the same rows (aliases dx)
+// The base chain runs in fp64 for both sweep precisions (it is the faster matrix-core form for 4 samples), then the
+// JVP chain; pointers arrive as generic ones (the function is not inlined: one copy per activation in the library)
+// and are put back into their address spaces first - flat loads would serialise LDS and global traffic.
+template <typename T, int ACT>
+__device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_generic, int lane) {
+  gf4p wq[3];
+  gfp bq[3];
+  gbfp jq[3];
+  int kgs[3], ots[3], jkss[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    wq[k] = (gf4p)uni64((unsigned long long)netv.wq[k]);
+    bq[k] = (gfp)uni64((unsigned long long)netv.bq[k]);
+    jq[k] = (gbfp)uni64((unsigned long long)netv.j[k]);
+    kgs[k] = uni(netv.kg[k]); ots[k] = uni(netv.ot[k]); jkss[k] = uni(netv.jks[k]);
+  }
+  const int L = uni(netv.L);
+  MJ_LDS unsigned char* sbase = (MJ_LDS unsigned char*)(unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned long long)(MJ_LDS unsigned char*)scratch_generic);
+  MJ_LDS T* xb = (MJ_LDS T*)sbase;
+  MJ_LDS float* actp = (MJ_LDS float*)(sbase + mj_xb_bytes<T>());
+  MJ_LDS unsigned char* dreg = sbase + mj_xb_bytes<T>() + MJ_ACTP_BYTES;
+  const MJ_LDS bf16x8* dx = (const MJ_LDS bf16x8*)dreg;
+  MJ_LDS float* dout = (MJ_LDS float*)dreg;
+  const int lo_ = L == 2 ? 1 : 2;
+  const int q = lane >> 4, c = lane & 15, j4 = lane & 3;
+  const int dunit = 4 * ((lane >> 2) & 3) + (lane >> 4);  // unit of this lane inside a D tile
+
+  double obase[MM_OUT_T][2];  // two partial sums per output tile (4 independent accumulators for the matrix pipe)
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2) { obase[o2][0] = (double)bq[lo_][o2 * 64 + lane]; obase[o2][1] = 0.0; }
+  f32x4 ojvp[MM_OUT_T][4];
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ojvp[o2][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto zero_dh = [](f32x4 (&dh)[4][4]) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dh[o][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto out_layer = [&](const double (&h)[4], const f32x4 (&wo4)[4][MM_OUT_T]) {
+    // output tiles from a 64-unit chunk; even / odd k-groups into separate partial sums
+    double a4[4] = {obase[0][0], obase[1][0], obase[0][1], obase[1][1]};
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double bv = chunk_operand(h, 4 * g + e);
+#pragma unroll
+        for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4((double)wo4[g][o2][e], bv, a4[2 * (g & 1) + o2]);
+      }
+    obase[0][0] = a4[0]; obase[1][0] = a4[1]; obase[0][1] = a4[2]; obase[1][1] = a4[3];
+  };
+
+  // base inputs as B operand: input 4 ks + (l >> 4) of sample l & 3 (the same in every block); k-step 7 is padding
+  double bin[8];
+#pragma unroll
+  for (int ks = 0; ks < MM_KS1; ++ks) bin[ks] = (double)xb[j4 * MJ_XB_LD + 4 * ks + q];
+  bin[7] = 0.0;
+
+  if (L == 2) {
+    // in -> H -> 25, hidden layer in chunks of 64 units that the output layer consumes at once
+    bf16x8 bdx[4][1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bdx[s][0] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+    const int chunks = ots[0] / 4;
+#pragma unroll 1
+    for (int ch = 0; ch < chunks; ++ch) {
+      f32x4 w1[2][4], wo4[4][MM_OUT_T];
+      base_load<4, 2>(w1, wq[0], 2, 4 * ch, 0, lane);
+      base_load<MM_OUT_T, 4>(wo4, wq[1], kgs[1], 0, 4 * ch, lane);
+      bf16x8 a1[1][4], ao[2][MM_OUT_T];
+      jvp_load<4, 1>(a1, jq[0], 1, 4 * ch, 0, lane);
+      jvp_load<MM_OUT_T, 2>(ao, jq[1], jkss[1], 0, 2 * ch, lane);
+      double h[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) h[o] = (double)bq[0][(4 * ch + o) * 64 + lane];
+      base_run<4, 2>(h, w1, [&](int ks) { return bin[ks]; });
+      chunk_activate<ACT>(h, actp, lane);
+      out_layer(h, wo4);
+      f32x4 dh[4][4];
+      zero_dh(dh);
+      jvp_accumulate<4, 1>(dh, a1, bdx);
+      mm_wave_sync();
+      bf16x8 b1[4][2];
+      jvp_scale_pack(dh, actp, lane, b1);
+      mm_wave_sync();  // (actp is rewritten by the next chunk)
+      jvp_accumulate<MM_OUT_T, 2>(ojvp, ao, b1);
+    }
+  } else {
+    // in -> H1 (<= 64: one chunk) -> H2 (<= 64 (MJ_ACT_SLOTS - 1)) -> 25: the whole base chain, then the whole JVP chain
+    const int chunks2 = ots[1] / 4;
+    f32x4 w1[2][4], w2[4][4], wo4[4][MM_OUT_T];
+    base_load<4, 2>(w1, wq[0], 2, 0, 0, lane);
+    base_load<4, 4>(w2, wq[1], 4, 0, 0, lane);
+    base_load<MM_OUT_T, 4>(wo4, wq[2], kgs[2], 0, 0, lane);
+    bf16x8 a1[1][4], a2[2][4], ao[2][MM_OUT_T];
+    jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
+    jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
+    jvp_load<MM_OUT_T, 2>(ao, jq[2], jkss[2], 0, 0, lane);
+    {
+      double h1[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) h1[o] = (double)bq[0][o * 64 + lane];
+      base_run<4, 2>(h1, w1, [&](int ks) { return bin[ks]; });
+      chunk_activate<ACT>(h1, actp, lane);
+#pragma unroll 1
+      for (int ch = 0; ch < chunks2; ++ch) {
+        if (ch > 0) {
+          base_load<4, 4>(w2, wq[1], 4, 4 * ch, 0, lane);
+          base_load<MM_OUT_T, 4>(wo4, wq[2], kgs[2], 0, 4 * ch, lane);
+        }
+        double h2[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h2[o] = (double)bq[1][(4 * ch + o) * 64 + lane];
+        base_run<4, 4>(h2, w2, [&](int ks) { return chunk_operand(h1, ks); });
+        chunk_activate<ACT>(h2, actp + (1 + ch) * 256, lane);
+        out_layer(h2, wo4);
+      }
+    }
+    mm_wave_sync();
+    bf16x8 b1[4][2];
+    {
+      bf16x8 bdx[4][1];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bdx[s][0] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+      f32x4 dh[4][4];
+      zero_dh(dh);
+      jvp_accumulate<4, 1>(dh, a1, bdx);
+      jvp_scale_pack(dh, actp, lane, b1);
+    }
+#pragma unroll 1
+    for (int ch = 0; ch < chunks2; ++ch) {
+      if (ch > 0) {
+        jvp_load<4, 2>(a2, jq[1], 2, 4 * ch, 0, lane);
+        jvp_load<MM_OUT_T, 2>(ao, jq[2], jkss[2], 0, 2 * ch, lane);
+      }
+      f32x4 dh[4][4];
+      zero_dh(dh);
+      jvp_accumulate<4, 2>(dh, a2, b1);
+      bf16x8 b2[4][2];
+      jvp_scale_pack(dh, actp + (1 + ch) * 256, lane, b2);
+      jvp_accumulate<MM_OUT_T, 2>(ojvp, ao, b2);
+    }
+  }
+  // results: base outputs over the input rows, J dx rows over the dx rows (every lane has read its operands; the
+  // sync orders the other lanes' reads before these writes)
+  mm_wave_sync();
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+    if (16 * o2 + dunit < 25) xb[j4 * MJ_XB_LD + 16 * o2 + dunit] = (T)(obase[o2][0] + obase[o2][1]);
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (16 * o2 + 4 * q < MJ_DOUT_LD)  // units 16 o2 + 4 q .. + 3 as one 16-byte store (28 .. 31 do not exist)
+        *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
+  mm_wave_sync();
+}
+
+// Per-lane wrapper.  iv / col: the lane's role (sub-interval, 0 = unperturbed); idle lanes pass col = 0 and a
+// copy of their interval's state.  x in, NN(x) (base lanes) or NN(x_base) + J dx (the others) out.
+template <typename T>
+__device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
+                                             bool idle, T (&out)[25]) {
+  using V = typename MjVec<T>::type;
+  constexpr int n = MjVec<T>::n;
+  T* xb = scratch;
+  unsigned char* dreg = reinterpret_cast<unsigned char*>(scratch) + mj_xb_bytes<T>() + MJ_ACTP_BYTES;
+  const bool base = col == 0 && !idle;
+  if (base) {
+    V* d = reinterpret_cast<V*>(xb + iv * MJ_XB_LD);
+#pragma unroll
+    for (int k = 0; k < MM_IN / n; ++k) {
+      V v;
+#pragma unroll
+      for (int e = 0; e < n; ++e) v[e] = x[k * n + e];
+      d[k] = v;
+    }
+  }
+  mm_wave_sync();
+  // dx row of this lane; the 10 lanes without a column (4 base, 6 idle) zero the 10 unused rows of sample tile 0
+  {
+    int row;
+    float d[MM_IN];
+    if (col > 0) {
+      row = 16 * iv + col - 1;
+      const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);
+#pragma unroll
+      for (int k = 0; k < MM_IN / n; ++k) {
+        const V v = b[k];
+#pragma unroll
+        for (int e = 0; e < n; ++e) d[k * n + e] = (float)(x[k * n + e] - v[e]);
+      }
+    } else {
+      row = 6 + (idle ? 4 + (lane - 58) : iv);
+#pragma unroll
+      for (int k = 0; k < MM_IN; ++k) d[k] = 0.f;
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* dst = reinterpret_cast<u32x4*>(dreg + (size_t)row * (MJ_DX_LD * 2));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      u32x4 p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 8 * v + 2 * e;
+        p[e] = k + 1 < MM_IN ? pack_bf2(d[k < MM_IN ? k : 0], d[k + 1 < MM_IN ? k + 1 : 0]) : 0u;
+      }
+      dst[v] = p;
+    }
+  }
+  mm_wave_sync();
+  const JvpNet net = jvp_net<T>(M);
+  switch (M.acts[0]) {  // wave-uniform
+    case KR_ACT_TANH: mlp_jvp_tile<T, KR_ACT_TANH>(net, scratch, lane); break;
+    case KR_ACT_SOFTPLUS: mlp_jvp_tile<T, KR_ACT_SOFTPLUS>(net, scratch, lane); break;
+    case KR_ACT_RELU: mlp_jvp_tile<T, KR_ACT_RELU>(net, scratch, lane); break;
+    case KR_ACT_ELU: mlp_jvp_tile<T, KR_ACT_ELU>(net, scratch, lane); break;
+    default: mlp_jvp_tile<T, KR_ACT_NONE>(net, scratch, lane); break;
+  }
+  {
+    const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);
+    constexpr int NB = (25 + n - 1) / n;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const V v = b[k];
+#pragma unroll
+      for (int e = 0; e < n; ++e)
+        if (k * n + e < 25) out[k * n + e] = v[e];
+    }
+    if (col > 0) {
+      const f32x4* dr = reinterpret_cast<const f32x4*>(dreg + (size_t)(16 * iv + col - 1) * (MJ_DOUT_LD * 4));
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const f32x4 v = dr[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * k + e < 25) out[4 * k + e] += (T)v[e];
+      }
+    }
+  }
+  mm_wave_sync();
+}
+
+}  // namespace kr

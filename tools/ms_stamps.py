@@ -9,8 +9,17 @@ import cosserat_oracle as orc, krod_native as kn
 from cosserat_ode import CosseratRod
 from knode import setup_robot
 B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 100, 120
+NN = len(sys.argv) > 2 and sys.argv[2] == "nn"   # MLP 28 -> 64 -> 64 -> 25 inside the sweeps
+if NN: T = 40
 dev = "cuda:0"; dt = torch.float64
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
+if NN:
+    mlp = orc.make_mlp([28, 64, 64, 25], "elu", seed=7)
+    model, params = [], []
+    for W_, b_, a_ in zip(mlp.weights, mlp.biases, mlp.acts):
+        model.append("Linear"); params += [W_, b_]
+        if a_ != orc.ACT_NONE: model.append("ELU(alpha=1.0)")
+    r.nn_model, r.param_ls, r.nn_path = model, params, "x"
 h = r._native(); h.set_option("ms_mode", 1); h.set_option("persistent", 1)
 dbg = torch.zeros((B, 24), dtype=torch.int64, device=dev)
 kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
@@ -18,9 +27,9 @@ ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 1235), device=dev).
 for pred in (7, 8):
     h.set_option("predictor", pred)
     st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
-    h.simulate(ctl[:, :21].contiguous(), st, G, ring=True)
+    h.simulate(ctl[:, :21].contiguous(), st, G, ring=True, use_nn=NN)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    h.simulate(ctl, st, G, ring=True, prev_init=st[2])
+    h.simulate(ctl, st, G, ring=True, prev_init=st[2], use_nn=NN)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     d = dbg.cpu().numpy().astype(np.float64)
     tot, sw, al, pr, its = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]

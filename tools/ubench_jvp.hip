@@ -1,0 +1,73 @@
+// Dev microbenchmark (GPU box): cycles of one wave-level base + JVP evaluation of the residual MLP (mlp_jvp.hpp), with
+// the chip loaded like the persistent kernel loads it (4 waves per workgroup, 256 workgroups), and with parts switched off.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../knode-cosserat_amd/csrc/mlp_jvp.hpp"
+namespace kr { void set_error(const std::string&) {} int hip_fail(hipError_t, const char*) { return -2; } int ensure_ws(kr_handle*, size_t) { return 0; } }
+using namespace kr;
+constexpr int WAVE = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void k(MlpDev<T> M, T* out, unsigned long long* cyc, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  T* scratch = reinterpret_cast<T*>(smem + (size_t)wv * ((mj_scratch_bytes<T>() + 15) & ~size_t(15)));
+  const bool idle = lane >= 58;
+  int iv = 0, col = 0;
+  if (lane < 7) { iv = 0; col = lane; } else if (!idle) { iv = 1 + (lane - 7) / 17; col = (lane - 7) % 17; }
+  T x[MM_IN];
+  for (int c = 0; c < MM_IN; ++c) x[c] = T(0.01) * (iv + c) + (col > 0 ? T(1e-7) * col : T(0));
+  T o[25];
+  for (int c = 0; c < 25; ++c) o[c] = 0;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  for (int it = 0; it < iters; ++it) {
+    T d[25];
+    mlp_jvp_eval<T>(M, x, scratch, lane, iv, col, idle, d);
+    for (int c = 0; c < 25; ++c) o[c] += d[c];
+    x[0] += d[0] * T(1e-9);
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  T s = 0;
+  for (int c = 0; c < 25; ++c) s += o[c];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <typename T>
+void run(const char* name, std::vector<int> dims, int blocks) {
+  const int L = (int)dims.size() - 1;
+  MlpDev<T> M{};
+  M.n_layers = L; M.mfma_ok = 1; M.jvp_ok = 1;
+  int prev = 0;
+  for (int kk = 0; kk < L; ++kk) {
+    const bool last = kk == L - 1;
+    const int tiles = last ? 2 : ((dims[kk + 1] + 63) / 64) * 4;
+    const int kg = kk == 0 ? 2 : prev;
+    const int jks = kk == 0 ? 1 : prev / 2;
+    float *w, *b; void* j;
+    (void)hipMalloc(&w, 16 * tiles * kg * 64); (void)hipMemset(w, 0, 16 * tiles * kg * 64);
+    (void)hipMalloc(&b, 4 * tiles * 64); (void)hipMemset(b, 0, 4 * tiles * 64);
+    (void)hipMalloc(&j, 16 * tiles * jks * 64); (void)hipMemset(j, 0, 16 * tiles * jks * 64);
+    M.wq[kk] = w; M.bq[kk] = b; M.kgroups[kk] = kg; M.otiles[kk] = tiles; M.acts[kk] = last ? KR_ACT_NONE : KR_ACT_ELU;
+    M.jfrag[kk] = j; M.jksteps[kk] = jks;
+    M.dims[kk] = dims[kk]; prev = tiles;
+  }
+  T* out; unsigned long long* cyc; (void)hipMalloc(&out, sizeof(T) * 256 * blocks); (void)hipMalloc(&cyc, 8 * blocks);
+  const int iters = 100;
+  const size_t smem = 4 * ((mj_scratch_bytes<T>() + 15) & ~size_t(15));
+  hipLaunchKernelGGL((k<T>), dim3(blocks), dim3(256), smem, 0, M, out, cyc, iters);
+  (void)hipDeviceSynchronize();
+  std::vector<unsigned long long> h(blocks); (void)hipMemcpy(h.data(), cyc, 8 * blocks, hipMemcpyDeviceToHost);
+  double s = 0; for (auto v : h) s += (double)v;
+  printf("%s blocks=%d: %.0f cycles per evaluation\n", name, blocks, s / blocks / iters);
+}
+int main() {
+  for (int blocks : {1, 256}) {
+    run<double>("f64 28-64-64-25", {28, 64, 64, 25}, blocks);
+    run<float>("f32 28-64-64-25", {28, 64, 64, 25}, blocks);
+  }
+  run<double>("f64 28-64-25", {28, 64, 25}, 256);
+  run<double>("f64 28-512-25", {28, 512, 25}, 256);
+  return 0;
+}
