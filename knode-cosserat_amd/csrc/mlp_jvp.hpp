@@ -24,6 +24,7 @@
 // j < 4, 32s + 16 + 4q + j - 4 otherwise); the host packs the next layer's bf16 weights in that k order, so no LDS
 // transpose is needed between layers.  The base chain keeps the layouts of mlp_mfma.hpp.
 #pragma once
+#include <type_traits>
 #include "mlp_mfma.hpp"
 
 namespace kr {
@@ -139,6 +140,16 @@ __device__ __forceinline__ double chunk_operand(const double (&h)[4], int ks) {
     default: return bcast_block<3>(v);
   }
 }
+// the same for all 16 k-steps at once: 32 swizzles issued back to back, one wait (pays where registers allow)
+__device__ __forceinline__ void chunk_operands(const double (&h)[4], double (&bv)[16]) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    bv[4 * o + 0] = bcast_block<0>(h[o]);
+    bv[4 * o + 1] = bcast_block<1>(h[o]);
+    bv[4 * o + 2] = bcast_block<2>(h[o]);
+    bv[4 * o + 3] = bcast_block<3>(h[o]);
+  }
+}
 // activation of a chunk (4 values per lane, all of them real) and its act' to the table [interval j][unit]
 template <int ACT>
 __device__ __forceinline__ void chunk_activate(double (&h)[4], MJ_LDS float* actp, int lane) {
@@ -239,14 +250,18 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
 #pragma unroll
       for (int s = 0; s < 4; ++s) dh[o][s] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto out_layer = [&](const double (&h)[4], const f32x4 (&wo4)[4][MM_OUT_T]) {
+  auto out_layer = [&](const double (&h)[4], const f32x4 (&wo4)[4][MM_OUT_T], auto batched) {
     // output tiles from a 64-unit chunk; even / odd k-groups into separate partial sums
     double a4[4] = {obase[0][0], obase[1][0], obase[0][1], obase[1][1]};
+    double bvs[16];
+    if constexpr (decltype(batched)::value) chunk_operands(h, bvs);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double bv = chunk_operand(h, 4 * g + e);
+        double bv;
+        if constexpr (decltype(batched)::value) bv = bvs[4 * g + e];
+        else bv = chunk_operand(h, 4 * g + e);
 #pragma unroll
         for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4((double)wo4[g][o2][e], bv, a4[2 * (g & 1) + o2]);
       }
@@ -278,7 +293,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
       for (int o = 0; o < 4; ++o) h[o] = (double)bq[0][(4 * ch + o) * 64 + lane];
       base_run<4, 2>(h, w1, [&](int ks) { return bin[ks]; });
       chunk_activate<ACT>(h, actp, lane);
-      out_layer(h, wo4);
+      out_layer(h, wo4, std::true_type{});
       f32x4 dh[4][4];
       zero_dh(dh);
       jvp_accumulate<4, 1>(dh, a1, bdx);
@@ -316,7 +331,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
         for (int o = 0; o < 4; ++o) h2[o] = (double)bq[1][(4 * ch + o) * 64 + lane];
         base_run<4, 4>(h2, w2, [&](int ks) { return chunk_operand(h1, ks); });
         chunk_activate<ACT>(h2, actp + (1 + ch) * 256, lane);
-        out_layer(h2, wo4);
+        out_layer(h2, wo4, std::false_type{});
       }
     }
     mm_wave_sync();
