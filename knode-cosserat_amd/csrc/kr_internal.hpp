@@ -174,7 +174,7 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
 
 // kr_mlp_fused.hip: fused fp32 MLP forward / backward for training
 bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad);
-size_t fused_ws_bytes(int n_layers, const int32_t* dims);
+size_t fused_ws_bytes(int n_layers, const int32_t* dims, int64_t Q);
 int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
                       const float* const* b, const float* x, float* out, void* ws, hipStream_t s);
 int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,

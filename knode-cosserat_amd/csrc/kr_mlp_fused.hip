@@ -43,32 +43,46 @@ __device__ __forceinline__ void fsync() {
 
 // ---- weight packing (device side, every call) ------------------------------------------------------
 // forward fragments: wf[(t*ks + s)*64 + lane] = W[16t + (lane&15)][unit_in(s, lane>>4)], bias fragments
-// bf[(t*4 + r)*64 + lane] = b[16t + 4*(lane>>4) + r]
-__global__ void pack_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b, int in, int out, int tiles,
-                                int ks, int first, float* __restrict__ wf, float* __restrict__ bf) {
-  const int n = tiles * ks * 64;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63, s = (i >> 6) % ks, t = (i >> 6) / ks;
-    const int uo = 16 * t + (lane & 15), q = lane >> 4;
-    const int ui = first ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
-    wf[i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
-  }
-  const int nb = tiles * 4 * 64;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63, r = (i >> 6) & 3, t = i >> 8;
-    const int u = 16 * t + 4 * (lane >> 4) + r;
-    bf[i] = u < out ? b[u] : 0.f;
-  }
-}
-// transposed fragments for dA_prev = W^T dZ: wt[(ti*ks + s)*64 + lane] = W[unit_out(s, q)][16*ti + (lane&15)]
-__global__ void pack_bwd_kernel(const float* __restrict__ W, int in, int out, int in_tiles, int ks, int natural,
-                                float* __restrict__ wt) {
-  const int n = in_tiles * ks * 64;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63, s = (i >> 6) % ks, ti = (i >> 6) / ks;
-    const int ui = 16 * ti + (lane & 15), q = lane >> 4;
-    const int uo = natural ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
-    wt[i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
+// bf[(t*4 + r)*64 + lane] = b[16t + 4*(lane>>4) + r]; transposed fragments for dA_prev = W^T dZ:
+// wt[(ti*ks + s)*64 + lane] = W[unit_out(s, q)][16*ti + (lane&15)].  One launch packs every layer (the packing
+// kernels are launch-latency bound: five of them cost 23 us of a 300 us epoch).
+struct PackArgs {
+  const float* W[3];
+  const float* b[3];
+  float* wf[3];
+  float* bf[3];
+  float* wt[3];
+  int in[3], out[3], tiles[3], ks[3], in_tiles[3], kst[3], natural[3];
+  int L;
+};
+__global__ void pack_all_kernel(const PackArgs P) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int k = 0; k < P.L; ++k) {
+    const float* __restrict__ W = P.W[k];
+    const int in = P.in[k], out = P.out[k], ks = P.ks[k];
+    const int n = P.tiles[k] * ks * 64;
+    for (int i = tid; i < n; i += nth) {
+      const int lane = i & 63, s = (i >> 6) % ks, t = (i >> 6) / ks;
+      const int uo = 16 * t + (lane & 15), q = lane >> 4;
+      const int ui = k == 0 ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
+      P.wf[k][i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
+    }
+    const int nb = P.tiles[k] * 4 * 64;
+    for (int i = tid; i < nb; i += nth) {
+      const int lane = i & 63, r = (i >> 6) & 3, t = i >> 8;
+      const int u = 16 * t + 4 * (lane >> 4) + r;
+      P.bf[k][i] = u < out ? P.b[k][u] : 0.f;
+    }
+    if (k > 0) {
+      const int kst = P.kst[k];
+      const int nt = P.in_tiles[k] * kst * 64;
+      for (int i = tid; i < nt; i += nth) {
+        const int lane = i & 63, s = (i >> 6) % kst, ti = (i >> 6) / kst;
+        const int ui = 16 * ti + (lane & 15), q = lane >> 4;
+        const int uo = P.natural[k] ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
+        P.wt[k][i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
+      }
+    }
   }
 }
 
@@ -185,7 +199,9 @@ __device__ __forceinline__ void wgrad(f4 (&acc)[NO][NI], const float* ta, int ld
       for (int i = 0; i < NI; ++i) acc[o][i] = mfma4(a[o], b[i], acc[o][i]);
   }
 }
-// accumulator tiles -> global dW[out][in] (nn.Linear layout) with float atomics
+// Weight gradients leave a wave ONCE, as plain stores into the wave's own slab of partial sums (nn.Linear layout);
+// reduce_slabs_kernel adds the slabs up afterwards.  (Round 1 flushed with float atomics: ~1000 wavefronts adding
+// 30 KB each into the same few rows serialise at the memory side - most of the backward kernel's time.)
 template <int NO, int NI>
 __device__ __forceinline__ void wgrad_flush(const f4 (&acc)[NO][NI], float* __restrict__ dW, int out, int in, int out0,
                                             int in0, int lane) {
@@ -196,7 +212,7 @@ __device__ __forceinline__ void wgrad_flush(const f4 (&acc)[NO][NI], float* __re
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int uo = out0 + 16 * o + 4 * (lane >> 4) + r, ui = in0 + 16 * i + (lane & 15);
-        if (uo < out && ui < in) atomicAdd(&dW[(size_t)uo * in + ui], acc[o][i][r]);
+        if (uo < out && ui < in) dW[(size_t)uo * in + ui] = acc[o][i][r];
       }
 }
 // per-lane partial column sums of a D-layout chunk (sum over its sample tiles)
@@ -215,7 +231,7 @@ __device__ __forceinline__ void bias_flush(const f4 (&p)[4], float* __restrict__
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
       const int u = out0 + 16 * o + 4 * (lane >> 4) + r;
-      if ((lane & 15) == 0 && u < out) atomicAdd(&db[u], v);
+      if ((lane & 15) == 0 && u < out) db[u] = v;
     }
 }
 
@@ -252,6 +268,10 @@ struct FusedArgs {
   int kst[3];            // k-steps of the transposed products
   float* dW[3];
   float* db[3];
+  float* slab;           // [streams][P] partial sums of every parameter gradient, P = all parameters of the network
+  int P, nslab, nparams;  // P: slab pitch (parameters rounded up to 64)
+  int poff[6];           // offsets of dW[0], db[0], dW[1], db[1], dW[2], db[2] inside a slab
+  float* dz2;            // three-layer backward: dZ2 of every row block between the two passes, [blocks][16][64] x 16 bytes
 };
 
 // ---- forward -------------------------------------------------------------------------------------------
@@ -318,143 +338,317 @@ __global__ __launch_bounds__(64) void mlp_fwd_fused_kernel(const FusedArgs A) {
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
-// L == 3: one wave handles whole networks (H1, H2 <= 64) over its row blocks.
-// L == 2: wave w handles hidden chunk w % c1 over the row blocks w / c1, w / c1 + G / c1, ...
-template <int ACT, int L>
-__global__ __launch_bounds__(64) void mlp_bwd_fused_kernel(const FusedArgs A) {
-  __shared__ __attribute__((aligned(16))) float tx[64 * F_LDX];
-  __shared__ __attribute__((aligned(16))) float td[64 * F_LDX];
-  __shared__ __attribute__((aligned(16))) float tu[64 * F_LDH];
-  __shared__ __attribute__((aligned(16))) float tv[64 * F_LDH];
-  const int lane = threadIdx.x;
-  const int64_t nblk = (A.Q + 63) / 64;
-  const int nchunk = L == 2 ? A.c1 : 1;
-  const int chunk = blockIdx.x % nchunk;
-  const int64_t rb0 = blockIdx.x / nchunk, rbstep = gridDim.x / nchunk;
-  if (rb0 >= nblk || rbstep == 0) return;
+// LDS tiles of the backward kernel are TRANSPOSED: T[unit][position], 64 positions per row, where position
+// p = 4 c + s stands for the sample that sits in column c of sample tile s of an accumulator (row 16 s + c of the
+// block).  Two things follow:
+//   * an accumulator chunk goes to its tile with one 16-byte store per (unit tile, register): the four sample tiles of
+//     a lane are four consecutive positions;
+//   * the weight-gradient contractions  dW += dZ^T A  take k-step kk as the positions {16 q + kk}: lane (unit i, q)
+//     reads the sixteen k-values of a tile as 4 x ds_read_b128 instead of 16 x ds_read_b32 - which sample is which k
+//     does not matter as long as both operands agree.
+// Rows are XOR-swizzled in 16-byte groups (group ^ sigma(unit & 15), sigma = swap of the two 2-bit halves) so that the
+// stores, the operand reads and the activation read-backs are all bank-conflict free.  40 KB per wave (X^T and dOUT^T
+// share one tile: X^T is staged a second time for dW1), one wave per SIMD.
+constexpr int TP = 64;
+__device__ __forceinline__ int tsig(int i) { return ((i & 3) << 2) | ((i >> 2) & 3); }
+__device__ __forceinline__ int tgrp(int u, int grp) { return u * TP + ((grp ^ tsig(u & 15)) << 2); }
 
-  // accumulators kept over all row blocks of this wave
-  f4 aW1[4][2];  // dW1 rows of this chunk x 32 input columns
+// accumulator chunk (4 unit tiles) -> T[unit][position]
+__device__ __forceinline__ void chunk_to_T(float* tile, const FChunk& h, int lane) {
+  const int c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
-  f4 aW2[4][4];  // L == 3: dW2 (64 x 64);  L == 2: [0..1][*] = dW2 (32 outputs x 64 hidden of this chunk)
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f4*>(tile + tgrp(16 * o + 4 * g + r, c)) = f4{h.a[o][0][r], h.a[o][1][r], h.a[o][2][r], h.a[o][3][r]};
+}
+// d *= act'(z) with act(z) read back from its tile
+template <int ACT>
+__device__ __forceinline__ void chunk_mul_grad_T(FChunk& d, const float* tile, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f4 a = *reinterpret_cast<const f4*>(tile + tgrp(16 * o + 4 * g + r, c));
+#pragma unroll
+      for (int sidx = 0; sidx < FT; ++sidx) d.a[o][sidx][r] *= grad_from_act<ACT>(a[sidx]);
+    }
+}
+// rows [row0, row0 + 64) of a row-major [Q][32] array -> T[32][position] (zero beyond Q); lane = row of the block
+__device__ __forceinline__ void stage_rows_T(const float* __restrict__ gsrc, int64_t row0, int64_t Q, float* tile, int lane) {
+  const int64_t row = row0 + lane;
+  const f4* src = reinterpret_cast<const f4*>(gsrc + row * F_LDX);
+  f4 v[F_LDX / 4];
+#pragma unroll
+  for (int k = 0; k < F_LDX / 4; ++k) v[k] = row < Q ? src[k] : f4{0.f, 0.f, 0.f, 0.f};
+  const int c = lane & 15, sidx = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < F_LDX / 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[tgrp(4 * k + e, c) + sidx] = v[k][e];
+}
+// B operands (natural k order) of the four sample tiles from T[32][position]: input 4 k + (lane >> 4)
+__device__ __forceinline__ void load_bops_T(float (&b)[FT][8], const float* tile, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const f4 v = *reinterpret_cast<const f4*>(tile + tgrp(4 * k + g, c));
+#pragma unroll
+    for (int sidx = 0; sidx < FT; ++sidx) b[sidx][k] = v[sidx];
+  }
+}
+// acc[o][i] += sum over the 64 positions of A[16 o + .][p] * B[16 i + .][p]   (both T tiles)
+template <int NO, int NI>
+__device__ __forceinline__ void wgrad_T(f4 (&acc)[NO][NI], const float* ta, const float* tb, int lane) {
+  const int u = lane & 15, q = lane >> 4;
+  // one 16-byte group (4 k-steps) of every operand tile at a time: NO + NI live operand registers x 4, and the
+  // scheduler is kept from hoisting all sixteen k-steps' reads (the kernel sits at the 256 architectural registers)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f4 av[NO], bv[NI];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) av[o] = *reinterpret_cast<const f4*>(ta + tgrp(16 * o + u, 4 * q + j));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bv[i] = *reinterpret_cast<const f4*>(tb + tgrp(16 * i + u, 4 * q + j));
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[o][i] = mfma4(av[o][e], bv[i][e], acc[o][i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Three-layer networks (H1, H2 <= 64) take two passes over the rows so that neither kernel needs more than the 256
+// architectural registers of a wave (one kernel for everything spilled 0.5 KB per lane):
+//   pass A   X -> A1 -> A2;  dW3 += dOUT^T A2;  dZ2 = (W3^T dOUT) * act'(Z2);  dW2 += dZ2^T A1;  db2, db3;
+//            dZ2 leaves as a raw register dump [block][tile][sample tile][lane] x 16 bytes (coalesced both ways)
+//   pass B   X -> A1 (layer 1 again: 10 % more matrix work);  dZ1 = (W2^T dZ2) * act'(Z1);  dW1 += dZ1^T X;  db1
+template <int ACT>
+__global__ __launch_bounds__(64) void mlp_bwd3a_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // X^T, then dOUT^T
+  __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1
+  __shared__ __attribute__((aligned(16))) float tv[64 * TP];  // A2 -> dZ2
+  const int lane = threadIdx.x;
+  const int64_t nblk = (A.Q + 63) / 64;
+  f4 aW2[4][4], aW3[2][4];
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int i = 0; i < 4; ++i) aW2[o][i] = f4{0.f, 0.f, 0.f, 0.f};
-  f4 aW3[2][4];  // L == 3: dW3 (32 outputs x 64 hidden)
 #pragma unroll
   for (int o = 0; o < 2; ++o)
 #pragma unroll
     for (int i = 0; i < 4; ++i) aW3[o][i] = f4{0.f, 0.f, 0.f, 0.f};
-  f4 pb1[4], pb2[4];
+  f4 pb2[4];
 #pragma unroll
-  for (int o = 0; o < 4; ++o) { pb1[o] = f4{0.f, 0.f, 0.f, 0.f}; pb2[o] = f4{0.f, 0.f, 0.f, 0.f}; }
-  float pbo = 0.f;  // bias gradient of the output layer, unit = lane (< 32), from the dOUT tile
-
-  for (int64_t rb = rb0; rb < nblk; rb += rbstep) {
-    stage_rows(A.x, rb * 64, A.Q, tx, lane);
-    stage_rows(A.dout, rb * 64, A.Q, td, lane);
+  for (int o = 0; o < 4; ++o) pb2[o] = f4{0.f, 0.f, 0.f, 0.f};
+  float pbo = 0.f;
+  for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
     fsync();
-    if (L == 3 || chunk == 0) {
-      if (lane < 32) {
-        float sacc = 0.f;
-        for (int rr = 0; rr < 64; ++rr) sacc += td[rr * F_LDX + lane];
-        pbo += sacc;
-      }
-    }
-    if constexpr (L == 3) {
+    {
+      FChunk h1;
       {
-        FChunk h1;
-        {
-          float bin[FT][8];
-          load_bops(bin, tx, lane);
-          chunk_set_bias(h1, A.bfr[0], 0, lane);
-          facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
-        }
-        chunk_act_only<ACT>(h1);
-        chunk_to_tile(tu, F_LDH, h1, lane);  // A1 [sample][unit]
-        FChunk h2;
-        chunk_set_bias(h2, A.bfr[1], 0, lane);
-        facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
-        chunk_act_only<ACT>(h2);
-        chunk_to_tile(tv, F_LDH, h2, lane);  // A2 [sample][unit]
-      }
-      fsync();
-      // dW3 += dOUT^T A2
-      wgrad<2, 4>(aW3, td, F_LDX, tv, F_LDH, lane);
-      // dZ2 = (W3^T dOUT) * act'(Z2)
-      FChunk d2;
-      chunk_zero(d2);
-      {
-        float bd[FT][8];
-        load_bops(bd, td, lane);
-        facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
-      }
-      chunk_mul_grad<ACT>(d2, tv, F_LDH, lane);
-      bias_partial(pb2, d2);
-      fsync();
-      chunk_to_tile(tv, F_LDH, d2, lane);  // dZ2 [sample][unit] (A2 is consumed)
-      fsync();
-      wgrad<4, 4>(aW2, tv, F_LDH, tu, F_LDH, lane);  // dW2 += dZ2^T A1
-      // dZ1 = (W2^T dZ2) * act'(Z1)
-      FChunk d1;
-      chunk_zero(d1);
-      facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
-      chunk_mul_grad<ACT>(d1, tu, F_LDH, lane);
-      bias_partial(pb1, d1);
-      fsync();
-      chunk_to_tile(tv, F_LDH, d1, lane);  // dZ1
-      fsync();
-      wgrad<4, 2>(aW1, tv, F_LDH, tx, F_LDX, lane);  // dW1 += dZ1^T X
-      fsync();
-    } else {
-      {
-        FChunk h1;
         float bin[FT][8];
-        load_bops(bin, tx, lane);
-        chunk_set_bias(h1, A.bfr[0], 4 * chunk, lane);
-        facc<4, 8>(h1.a, A.wf[0], 8, 4 * chunk, 0, lane, [&](int s, int k) { return bin[s][k]; });
-        chunk_act_only<ACT>(h1);
-        chunk_to_tile(tu, F_LDH, h1, lane);  // A1 chunk [sample][unit]
+        load_bops_T(bin, ts, lane);
+        chunk_set_bias(h1, A.bfr[0], 0, lane);
+        facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
       }
-      fsync();
-      // dW2[:, chunk] += dOUT^T A1
-      f4(&aWo)[2][4] = reinterpret_cast<f4(&)[2][4]>(aW2);
-      wgrad<2, 4>(aWo, td, F_LDX, tu, F_LDH, lane);
-      // dZ1 = (W2^T[chunk] dOUT) * act'(Z1)
-      FChunk d1;
-      chunk_zero(d1);
-      {
-        float bd[FT][8];
-        load_bops(bd, td, lane);
-        facc<4, 8>(d1.a, A.wt[1], A.kst[1], 4 * chunk, 0, lane, [&](int s, int k) { return bd[s][k]; });
-      }
-      chunk_mul_grad<ACT>(d1, tu, F_LDH, lane);
-      bias_partial(pb1, d1);
-      chunk_to_tile(tv, F_LDH, d1, lane);
-      fsync();
-      wgrad<4, 2>(aW1, tv, F_LDH, tx, F_LDX, lane);  // dW1[chunk] += dZ1^T X
-      fsync();
+      fsync();  // X^T has been read by every lane: dOUT^T may overwrite it
+      stage_rows_T(A.dout, rb * 64, A.Q, ts, lane);
+      chunk_act_only<ACT>(h1);
+      chunk_to_T(tu, h1, lane);
+      FChunk h2;
+      chunk_set_bias(h2, A.bfr[1], 0, lane);
+      facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
+      chunk_act_only<ACT>(h2);
+      chunk_to_T(tv, h2, lane);
     }
+    fsync();
+    if (lane < 32) {
+      f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int grp = 0; grp < 16; ++grp) sacc = sacc + *reinterpret_cast<const f4*>(ts + lane * TP + 4 * grp);
+      pbo += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+    }
+    wgrad_T<2, 4>(aW3, ts, tv, lane);  // dW3 += dOUT^T A2
+    FChunk d2;
+    chunk_zero(d2);
+    {
+      float bd[FT][8];
+      load_bops_T(bd, ts, lane);
+      facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
+    }
+    chunk_mul_grad_T<ACT>(d2, tv, lane);
+    bias_partial(pb2, d2);
+    {
+      f4* dst = reinterpret_cast<f4*>(A.dz2) + (size_t)rb * (16 * 64) + lane;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int sidx = 0; sidx < FT; ++sidx) dst[(o * FT + sidx) * 64] = d2.a[o][sidx];
+    }
+    fsync();
+    chunk_to_T(tv, d2, lane);  // dZ2 (A2 is consumed)
+    fsync();
+    wgrad_T<4, 4>(aW2, tv, tu, lane);  // dW2 += dZ2^T A1
+    fsync();
   }
-  // ---- one flush per wave ------------------------------------------------------------------------------
-  if constexpr (L == 3) {
-    wgrad_flush<2, 4>(aW3, A.dW[2], A.nout, A.h2, 0, 0, lane);
-    wgrad_flush<4, 4>(aW2, A.dW[1], A.h2, A.h1, 0, 0, lane);
-    wgrad_flush<4, 2>(aW1, A.dW[0], A.h1, A.in, 0, 0, lane);
-    bias_flush(pb2, A.db[1], A.h2, 0, lane);
-    bias_flush(pb1, A.db[0], A.h1, 0, lane);
-    if (lane < A.nout) atomicAdd(&A.db[2][lane], pbo);
-  } else {
-    const f4(&aWo)[2][4] = reinterpret_cast<const f4(&)[2][4]>(aW2);
-    wgrad_flush<2, 4>(aWo, A.dW[1], A.nout, A.h1, 0, 64 * chunk, lane);
-    wgrad_flush<4, 2>(aW1, A.dW[0], A.h1, A.in, 64 * chunk, 0, lane);
-    bias_flush(pb1, A.db[0], A.h1, 64 * chunk, lane);
-    if (chunk == 0 && lane < A.nout) atomicAdd(&A.db[1][lane], pbo);
+  float* slab = A.slab + (size_t)blockIdx.x * A.P;
+  wgrad_flush<2, 4>(aW3, slab + A.poff[4], A.nout, A.h2, 0, 0, lane);
+  wgrad_flush<4, 4>(aW2, slab + A.poff[2], A.h2, A.h1, 0, 0, lane);
+  bias_flush(pb2, slab + A.poff[3], A.h2, 0, lane);
+  if (lane < A.nout) slab[A.poff[5] + lane] = pbo;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(64) void mlp_bwd3b_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // X^T
+  __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1 -> dZ1
+  const int lane = threadIdx.x;
+  const int64_t nblk = (A.Q + 63) / 64;
+  f4 aW1[4][2];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 pb1[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) pb1[o] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
+    FChunk d2;
+    {
+      const f4* src = reinterpret_cast<const f4*>(A.dz2) + (size_t)rb * (16 * 64) + lane;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int sidx = 0; sidx < FT; ++sidx) d2.a[o][sidx] = src[(o * FT + sidx) * 64];
+    }
+    fsync();
+    {
+      FChunk h1;
+      float bin[FT][8];
+      load_bops_T(bin, ts, lane);
+      chunk_set_bias(h1, A.bfr[0], 0, lane);
+      facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      chunk_act_only<ACT>(h1);
+      chunk_to_T(tu, h1, lane);
+    }
+    FChunk d1;
+    chunk_zero(d1);
+    facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
+    fsync();
+    chunk_mul_grad_T<ACT>(d1, tu, lane);
+    bias_partial(pb1, d1);
+    fsync();
+    chunk_to_T(tu, d1, lane);  // dZ1 (A1 is consumed)
+    fsync();
+    wgrad_T<4, 2>(aW1, tu, ts, lane);  // dW1 += dZ1^T X
+    fsync();
   }
+  float* slab = A.slab + (size_t)blockIdx.x * A.P;
+  wgrad_flush<4, 2>(aW1, slab + A.poff[0], A.h1, A.in, 0, 0, lane);
+  bias_flush(pb1, slab + A.poff[1], A.h1, 0, lane);
+}
+
+// Two-layer networks in -> H1 -> out with any H1: wave w handles hidden chunk w % c1 (64 units) over the row blocks
+// w / c1, w / c1 + G / c1, ...
+template <int ACT>
+__global__ __launch_bounds__(64) void mlp_bwd2_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // X^T, then dOUT^T, then X^T again
+  __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1
+  __shared__ __attribute__((aligned(16))) float tv[64 * TP];  // dZ1
+  const int lane = threadIdx.x;
+  const int64_t nblk = (A.Q + 63) / 64;
+  const int nchunk = A.c1;
+  const int chunk = blockIdx.x % nchunk;
+  const int64_t rb0 = blockIdx.x / nchunk, rbstep = gridDim.x / nchunk;
+  if (rb0 >= nblk || rbstep == 0) return;
+  f4 aW1[4][2], aWo[2][4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aWo[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 pb1[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) pb1[o] = f4{0.f, 0.f, 0.f, 0.f};
+  float pbo = 0.f;
+  for (int64_t rb = rb0; rb < nblk; rb += rbstep) {
+    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
+    fsync();
+    {
+      FChunk h1;
+      float bin[FT][8];
+      load_bops_T(bin, ts, lane);
+      chunk_set_bias(h1, A.bfr[0], 4 * chunk, lane);
+      facc<4, 8>(h1.a, A.wf[0], 8, 4 * chunk, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      fsync();
+      stage_rows_T(A.dout, rb * 64, A.Q, ts, lane);
+      chunk_act_only<ACT>(h1);
+      chunk_to_T(tu, h1, lane);  // A1 chunk
+    }
+    fsync();
+    if (chunk == 0 && lane < 32) {
+      f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int grp = 0; grp < 16; ++grp) sacc = sacc + *reinterpret_cast<const f4*>(ts + lane * TP + 4 * grp);
+      pbo += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+    }
+    wgrad_T<2, 4>(aWo, ts, tu, lane);  // dW2[:, chunk] += dOUT^T A1
+    // dZ1 = (W2^T[chunk] dOUT) * act'(Z1)
+    FChunk d1;
+    chunk_zero(d1);
+    {
+      float bd[FT][8];
+      load_bops_T(bd, ts, lane);
+      facc<4, 8>(d1.a, A.wt[1], A.kst[1], 4 * chunk, 0, lane, [&](int s, int k) { return bd[s][k]; });
+    }
+    chunk_mul_grad_T<ACT>(d1, tu, lane);
+    bias_partial(pb1, d1);
+    fsync();
+    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
+    chunk_to_T(tv, d1, lane);
+    fsync();
+    wgrad_T<4, 2>(aW1, tv, ts, lane);  // dW1[chunk] += dZ1^T X
+    fsync();
+  }
+  float* slab = A.slab + (size_t)rb0 * A.P;  // one slab per row-block stream; its chunks write disjoint parts
+  wgrad_flush<2, 4>(aWo, slab + A.poff[2], A.nout, A.h1, 0, 64 * chunk, lane);
+  wgrad_flush<4, 2>(aW1, slab + A.poff[0], A.h1, A.in, 64 * chunk, 0, lane);
+  bias_flush(pb1, slab + A.poff[1], A.h1, 64 * chunk, lane);
+  if (chunk == 0 && lane < A.nout) slab[A.poff[3] + lane] = pbo;
+}
+
+// dW[k] += sum over the slabs.  Thread (parameter i, group g) adds up the slabs g, g + RG, g + 2 RG, ... (consecutive
+// threads read consecutive floats of a slab) and contributes with ONE float atomic: RG adders per address, spread
+// over the whole parameter range - the uncontended regime of the memory-side atomics.
+constexpr int RG = 32;
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const FusedArgs A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= A.nparams) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int w = g;
+  for (; w + 3 * RG < A.nslab; w += 4 * RG) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += A.slab[(size_t)(w + e * RG) * A.P + i];
+  }
+  for (; w < A.nslab; w += RG) acc[0] += A.slab[(size_t)w * A.P + i];
+  const float sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  int seg = 5;
+#pragma unroll
+  for (int k = 4; k >= 0; --k)
+    if (i < A.poff[k + 1]) seg = k;
+  float* dst = (seg & 1) ? A.db[seg >> 1] : A.dW[seg >> 1];
+  atomicAdd(&dst[i - A.poff[seg]], sum);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -480,7 +674,14 @@ static size_t fused_frag_floats(int n_layers, const int32_t* dims) {
   }
   return n;
 }
-size_t fused_ws_bytes(int n_layers, const int32_t* dims) { return fused_frag_floats(n_layers, dims) * sizeof(float) + 256; }
+size_t fused_ws_bytes(int n_layers, const int32_t* dims, int64_t Q) {
+  size_t n = ((fused_frag_floats(n_layers, dims) + 63) & ~size_t(63)) * sizeof(float) + 256;
+  if (n_layers == 3) n += (size_t)((Q + 63) / 64) * 16 * 64 * 16;  // dZ2 between the two backward passes
+  size_t P = 0;
+  for (int k = 0; k < n_layers; ++k) P += (size_t)dims[k] * dims[k + 1] + dims[k + 1];
+  n += 1024 * ((P + 63) & ~size_t(63)) * sizeof(float);  // slabs of partial weight gradients
+  return n;
+}
 
 // lays the fragment buffers out in `ws`; do_pack launches the packing kernels (forward call), otherwise
 // the fragments packed by the matching forward call are reused (backward call)
@@ -494,27 +695,27 @@ static int fused_pack(FusedArgs& A, int n_layers, const int32_t* dims, const flo
   A.c1 = (dims[1] + 63) / 64;
   float* p = ws;
   int prev_tiles = 2;
+  PackArgs PA{};
+  PA.L = n_layers;
   for (int k = 0; k < n_layers; ++k) {
     const bool last = k == n_layers - 1;
     const int tiles = last ? 2 : ((dims[k + 1] + 63) / 64) * 4;
     const int ks = k == 0 ? 8 : prev_tiles * 4;
     float* wf = p; p += (size_t)tiles * ks * 64;
     float* bf = p; p += (size_t)tiles * 4 * 64;
-    if (do_pack)
-      hipLaunchKernelGGL(pack_fwd_kernel, dim3(64), dim3(256), 0, s, W[k], b[k], dims[k], dims[k + 1], tiles, ks,
-                         k == 0 ? 1 : 0, wf, bf);
     A.wf[k] = wf; A.bfr[k] = bf; A.ks[k] = ks;
+    PA.W[k] = W[k]; PA.b[k] = b ? b[k] : nullptr; PA.wf[k] = wf; PA.bf[k] = bf;
+    PA.in[k] = dims[k]; PA.out[k] = dims[k + 1]; PA.tiles[k] = tiles; PA.ks[k] = ks;
     if (k > 0) {
       // dA_{k-1}[in unit][sample] = sum_out W_k[out][in] dZ_k[out][sample]: k-steps run over the outputs of layer k
       const int kst = last ? 8 : tiles * 4;
       float* wt = p; p += (size_t)prev_tiles * kst * 64;
-      if (do_pack)
-        hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, s, W[k], dims[k], dims[k + 1], prev_tiles, kst,
-                           last ? 1 : 0, wt);
       A.wt[k] = wt; A.kst[k] = kst;
+      PA.wt[k] = wt; PA.in_tiles[k] = prev_tiles; PA.kst[k] = kst; PA.natural[k] = last ? 1 : 0;
     }
     prev_tiles = tiles;
   }
+  if (do_pack) hipLaunchKernelGGL(pack_all_kernel, dim3(64), dim3(256), 0, s, PA);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }
@@ -556,15 +757,39 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
   const int64_t nblk = (Q + 63) / 64;
   const int nchunk = n_layers == 2 ? A.c1 : 1;
   int64_t waves = nblk * nchunk;
-  if (waves > 768) waves = 768 / nchunk * nchunk;  // 3 workgroups of 48 KB LDS per CU
+  if (waves > 1024) waves = 1024 / nchunk * nchunk;  // 4 workgroups of 40 KB LDS per CU: one wave per SIMD
   if (waves < nchunk) waves = nchunk;
   const int grid = (int)waves;
-  launch_by_act(acts[0], [&](auto act) {
-    if (n_layers == 3)
-      hipLaunchKernelGGL((mlp_bwd_fused_kernel<decltype(act)::value, 3>), dim3(grid), dim3(64), 0, s, A);
-    else
-      hipLaunchKernelGGL((mlp_bwd_fused_kernel<decltype(act)::value, 2>), dim3(grid), dim3(64), 0, s, A);
-  });
+  // workspace behind the packed fragments: [dZ2 between the two passes of a three-layer network] [gradient slabs]
+  float* wsf = static_cast<float*>(ws) + ((fused_frag_floats(n_layers, dims) + 63) & ~size_t(63));
+  if (n_layers == 3) {
+    A.dz2 = wsf;
+    wsf += (size_t)nblk * 16 * 64 * 4;
+  }
+  int P = 0;
+  for (int k = 0; k < n_layers; ++k) {
+    A.poff[2 * k] = P; P += dims[k] * dims[k + 1];
+    A.poff[2 * k + 1] = P; P += dims[k + 1];
+  }
+  for (int k = 2 * n_layers; k < 6; ++k) A.poff[k] = P;
+  A.nparams = P;
+  A.P = (P + 63) & ~63;
+  A.slab = wsf;
+  if (n_layers == 3) {
+    const int grid3 = (int)(nblk < 1024 ? nblk : 1024);
+    A.nslab = grid3;
+    launch_by_act(acts[0], [&](auto act) {
+      hipLaunchKernelGGL((mlp_bwd3a_kernel<decltype(act)::value>), dim3(grid3), dim3(64), 0, s, A);
+      hipLaunchKernelGGL((mlp_bwd3b_kernel<decltype(act)::value>), dim3(grid3), dim3(64), 0, s, A);
+    });
+  } else {
+    const int64_t streams = grid / nchunk;
+    A.nslab = (int)(streams < nblk ? streams : nblk);  // streams beyond the row blocks exit without a slab
+    launch_by_act(acts[0], [&](auto act) {
+      hipLaunchKernelGGL((mlp_bwd2_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
+    });
+  }
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P + 255) / 256, RG), dim3(256), 0, s, A);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }

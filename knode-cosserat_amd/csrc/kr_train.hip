@@ -484,7 +484,7 @@ size_t kr_mlp_ws_bytes(int n_layers, const int32_t* dims, int64_t Q) {
   if (n_layers < 1 || n_layers > KR_MAX_LAYERS || !dims || Q <= 0) return 0;
   size_t n = carve_ws(nullptr, n_layers, dims, Q).bytes;
   if (n_layers == 2 || n_layers == 3) {
-    const size_t f = fused_ws_bytes(n_layers, dims);
+    const size_t f = fused_ws_bytes(n_layers, dims, Q);
     if (f > n) n = f;
   }
   return n;
