@@ -290,6 +290,14 @@ int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, cons
                          const float* target_rows, double denom, float* pred, float* loss, float* dout,
                          void* stream);
 
+/* Full-state estimate from measured poses, knode_cosserat_realworld/estimate_state.py:158-242 (with compute_v_u
+ * :48-95, compute_angular_velocities :97-123, compute_internal_forces_and_moments :126-156): data[T][7][N]
+ * (positions, quaternions at the handle's N grid points), tensions[T][4] -> est[T][25][N], fp64, device pointers.
+ * ws: kr_estimate_ws_bytes(T, N) bytes of device scratch.  Uses the handle's parameters (L, del_t, C, Bse, Bbt, ...). */
+size_t kr_estimate_ws_bytes(int64_t T, int N);
+int kr_estimate_state(kr_handle* h, int64_t T, const double* data, const double* tensions, double* est, void* ws,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,3 +449,44 @@ def test_data_parallel_more_ranks_than_trajectories(torch_cuda, tmp_path):
     assert abs(ck_cont["loss"][-1] - ck_full["loss"][-1]) <= 1e-4 * abs(ck_full["loss"][-1])
     for a, b in zip(ck_cont["robot"].nn_models.parameters(), ck_full["robot"].nn_models.parameters()):
         assert rel_l2(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("N", [10, 12])
+def test_estimate_state_on_device(torch_cuda, N):
+    """kr_estimate_state (four fp64 kernels) against knode_cosserat_realworld/estimate_state.py:158-242 run by the
+    reference (fixture estimate_state.npz: N = 10, the size its literal index 9 is meant for, and N = 12, where the
+    backward integration wraps into the tip entry), and against the CPU oracle on a longer random input."""
+    import krod_estimate as kest
+    import estimate_oracle as eor
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot
+    g = load_golden("estimate_state")
+    r = CosseratRod(use_fsolve=True)
+    setup_robot(r)
+    r.N = N
+    r.compute_intermediate_terms()
+    est = kest.estimate_state(g[f"N{N}_data"], g[f"N{N}_ctl"], r)
+    want = g[f"N{N}_est"]
+    assert est.shape == want.shape and est.dtype == np.float64
+    for rows, name in ((slice(0, 7), "p,h"), (slice(13, 19), "q,w"), (slice(7, 13), "n,m"), (slice(19, 25), "v,u")):
+        assert rel_l2(est[:, rows], want[:, rows]) < 1e-9, name
+    assert np.allclose(np.asarray(r.vstar, dtype=np.float64), g[f"N{N}_vstar_after"], rtol=0, atol=1e-12)
+    # longer input, both implementations: T = 300 steps of jittered poses
+    rng = np.random.default_rng(N)
+    reps = int(np.ceil(300 / g[f"N{N}_data"].shape[0]))
+    data = np.concatenate([g[f"N{N}_data"]] * reps)[:300] + 1e-4 * rng.standard_normal((300, 7, N))
+    ctl = np.concatenate([g[f"N{N}_ctl"]] * reps)[:300]
+    r2 = CosseratRod(use_fsolve=True)
+    setup_robot(r2, "damping")
+    r2.N = N
+    r2.compute_intermediate_terms()
+    r3 = CosseratRod(use_fsolve=True)
+    setup_robot(r3, "damping")
+    r3.N = N
+    r3.compute_intermediate_terms()
+    a = kest.estimate_state(data, ctl, r2)
+    b = eor.estimate_state(data, ctl, r3)
+    for rows in (slice(0, 7), slice(13, 19), slice(7, 13), slice(19, 25)):
+        assert rel_l2(a[:, rows], b[:, rows]) < 1e-9
+    with pytest.raises(Exception):
+        kest.estimate_state(data[:, :, :-1], ctl, r2)

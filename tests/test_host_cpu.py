@@ -354,10 +354,10 @@ def test_legacy_preset_table():
 
 
 @pytest.mark.parametrize("N", [10, 12])
-def test_estimate_state_matches_reference(N):
-    """krod_estimate.estimate_state against knode_cosserat_realworld/estimate_state.py:158-242 run by the
-    reference (fixture estimate_state.npz); host-side, needs only kr_derive from the library."""
-    import krod_estimate as kest
+def test_estimate_state_oracle_matches_reference(N):
+    """oracle/estimate_oracle.py (the checker of the device implementation) against
+    knode_cosserat_realworld/estimate_state.py:158-242 run by the reference (fixture estimate_state.npz)."""
+    import estimate_oracle as kest
     from cosserat_ode import CosseratRod
     from knode import setup_robot
     g = load_golden("estimate_state")
