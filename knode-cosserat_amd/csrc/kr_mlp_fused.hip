@@ -26,7 +26,16 @@
 namespace kr {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int FT = 4;        // sample tiles per row block (64 rows)
+#ifndef KR_FUSED_FT
+#define KR_FUSED_FT 2
+#endif
+constexpr int FT = KR_FUSED_FT;  // sample tiles per row block (2 or 4): 16 FT rows.  2 halves the LDS tiles and the
+                                 // register chunks of a wave, which buys the second wave per SIMD (the kernels alternate
+                                 // matrix-pipe phases with vector / LDS phases: one wave leaves the pipe idle two thirds of the time)
+static_assert(FT == 2 || FT == 4, "row blocks of 32 or 64 samples");
+constexpr int FR = 16 * FT;  // rows per block
+constexpr int F_MAXW = FT == 2 ? 2048 : 1024;  // backward wavefronts resident at once: LDS 20 / 40 KB each
+typedef float fvT __attribute__((ext_vector_type(FT)));  // the FT samples a lane holds of one unit
 constexpr int FPD = 3;       // prefetch distance of weight fragments, in k-steps
 constexpr int F_LDX = 32;    // row length of the X / dOUT tiles
 constexpr int F_LDH = 64;    // row length of the hidden tiles
@@ -106,6 +115,9 @@ __device__ __forceinline__ void facc(f4 (&dst)[NO][FT], const float* __restrict_
     for (int o = 0; o < NO; ++o)
 #pragma unroll
       for (int s = 0; s < FT; ++s) dst[o][s] = mfma4(a[k][o], bsrc(s, k), dst[o][s]);
+    // keep the software pipeline as written: left alone, the scheduler hoists every fragment load of the chain to its
+    // head and the kernel no longer fits two waves per SIMD
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 __device__ __forceinline__ void chunk_set_bias(FChunk& h, const float* __restrict__ bf, int tile0, int lane) {
@@ -243,13 +255,32 @@ __device__ __forceinline__ void load_bops(float (&b)[FT][8], const float* tile, 
     for (int k = 0; k < 8; ++k) b[s][k] = tile[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
 }
 
-// rows [row0, row0+64) of a row-major [Q][32] array -> LDS tile (zero beyond Q)
+// rows [row0, row0 + FR) of a row-major [Q][32] array -> LDS tile (zero beyond Q); 64 / FR lanes share a row
 __device__ __forceinline__ void stage_rows(const float* __restrict__ g, int64_t row0, int64_t Q, float* tile, int lane) {
-  const int64_t row = row0 + lane;
-  const f4* src = reinterpret_cast<const f4*>(g + row * F_LDX);
-  f4* dst = reinterpret_cast<f4*>(tile + lane * F_LDX);
+  constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;
+  const int rl = lane % FR, part = lane / FR;
+  const int64_t row = row0 + rl;
+  const f4* src = reinterpret_cast<const f4*>(g + row * F_LDX) + part * NV;
+  f4* dst = reinterpret_cast<f4*>(tile + rl * F_LDX) + part * NV;
 #pragma unroll
-  for (int c = 0; c < F_LDX / 4; ++c) dst[c] = row < Q ? src[c] : f4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < NV; ++c) dst[c] = row < Q ? src[c] : f4{0.f, 0.f, 0.f, 0.f};
+}
+
+// raw register image of a chunk, [block][unit tile][sample tile][lane] x 16 bytes: coalesced both ways, and exactly
+// the layout the consumer needs as B operand / for its T tile
+__device__ __forceinline__ void chunk_dump(float* __restrict__ base, int64_t rb, const FChunk& h, int lane) {
+  f4* dst = reinterpret_cast<f4*>(base) + (size_t)rb * (4 * FT * 64) + lane;
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int sidx = 0; sidx < FT; ++sidx) dst[(o * FT + sidx) * 64] = h.a[o][sidx];
+}
+__device__ __forceinline__ void chunk_undump(FChunk& h, const float* __restrict__ base, int64_t rb, int lane) {
+  const f4* src = reinterpret_cast<const f4*>(base) + (size_t)rb * (4 * FT * 64) + lane;
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int sidx = 0; sidx < FT; ++sidx) h.a[o][sidx] = src[(o * FT + sidx) * 64];
 }
 
 struct FusedArgs {
@@ -271,17 +302,19 @@ struct FusedArgs {
   float* slab;           // [streams][P] partial sums of every parameter gradient, P = all parameters of the network
   int P, nslab, nparams;  // P: slab pitch (parameters rounded up to 64)
   int poff[6];           // offsets of dW[0], db[0], dW[1], db[1], dW[2], db[2] inside a slab
+  float* a1d;            // three-layer networks: hidden activations A1, A2 of every row block as register images, written
+  float* a2d;            // by the forward kernel and read by the backward passes (HBM is idle here, the matrix pipe is not)
   float* dz2;            // three-layer backward: dZ2 of every row block between the two passes, [blocks][16][64] x 16 bytes
 };
 
 // ---- forward -------------------------------------------------------------------------------------------
 template <int ACT>
-__global__ __launch_bounds__(64) void mlp_fwd_fused_kernel(const FusedArgs A) {
-  __shared__ __attribute__((aligned(16))) float tx[64 * F_LDX];
+__global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float tx[FR * F_LDX];
   const int lane = threadIdx.x;
-  const int64_t nblk = (A.Q + 63) / 64;
+  const int64_t nblk = (A.Q + FR - 1) / FR;
   for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
-    stage_rows(A.x, rb * 64, A.Q, tx, lane);
+    stage_rows(A.x, rb * FR, A.Q, tx, lane);
     fsync();
     float bin[FT][8];
 #pragma unroll
@@ -310,9 +343,11 @@ __global__ __launch_bounds__(64) void mlp_fwd_fused_kernel(const FusedArgs A) {
       chunk_set_bias(h1, A.bfr[0], 0, lane);
       facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
       chunk_act_only<ACT>(h1);
+      chunk_dump(A.a1d, rb, h1, lane);
       chunk_set_bias(h2, A.bfr[1], 0, lane);
       facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
       chunk_act_only<ACT>(h2);
+      chunk_dump(A.a2d, rb, h2, lane);
       facc<2, 16>(oacc, A.wf[2], A.ks[2], 0, 0, lane, [&](int s, int k) { return h2.a[k >> 2][s][k & 3]; });
     }
     fsync();
@@ -326,12 +361,16 @@ __global__ __launch_bounds__(64) void mlp_fwd_fused_kernel(const FusedArgs A) {
           tx[(16 * s + (lane & 15)) * F_LDX + u] = u < A.nout ? oacc[o][s][r] : 0.f;
         }
     fsync();
-    const int64_t row = rb * 64 + lane;
-    if (row < A.Q) {
-      const f4* src = reinterpret_cast<const f4*>(tx + lane * F_LDX);
-      f4* dst = reinterpret_cast<f4*>(A.out + row * F_LDX);
+    {
+      constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;  // lanes per row, 16-byte pieces per lane
+      const int rl = lane % FR, part = lane / FR;
+      const int64_t row = rb * FR + rl;
+      if (row < A.Q) {
+        const f4* src = reinterpret_cast<const f4*>(tx + rl * F_LDX) + part * NV;
+        f4* dst = reinterpret_cast<f4*>(A.out + row * F_LDX) + part * NV;
 #pragma unroll
-      for (int c = 0; c < F_LDX / 4; ++c) dst[c] = src[c];
+        for (int c = 0; c < NV; ++c) dst[c] = src[c];
+      }
     }
     fsync();
   }
@@ -349,9 +388,12 @@ __global__ __launch_bounds__(64) void mlp_fwd_fused_kernel(const FusedArgs A) {
 // Rows are XOR-swizzled in 16-byte groups (group ^ sigma(unit & 15), sigma = swap of the two 2-bit halves) so that the
 // stores, the operand reads and the activation read-backs are all bank-conflict free.  40 KB per wave (X^T and dOUT^T
 // share one tile: X^T is staged a second time for dW1), one wave per SIMD.
-constexpr int TP = 64;
+constexpr int TP = 16 * FT;   // positions per row
+constexpr int TNG = TP / 4;   // 16-byte groups per row
 __device__ __forceinline__ int tsig(int i) { return ((i & 3) << 2) | ((i >> 2) & 3); }
-__device__ __forceinline__ int tgrp(int u, int grp) { return u * TP + ((grp ^ tsig(u & 15)) << 2); }
+__device__ __forceinline__ int tgrp(int u, int grp) { return u * TP + ((grp ^ (tsig(u & 15) & (TNG - 1))) << 2); }
+// address of position p of row u
+__device__ __forceinline__ int tpos(int u, int p) { return tgrp(u, p >> 2) + (p & 3); }
 
 // accumulator chunk (4 unit tiles) -> T[unit][position]
 __device__ __forceinline__ void chunk_to_T(float* tile, const FChunk& h, int lane) {
@@ -359,8 +401,12 @@ __device__ __forceinline__ void chunk_to_T(float* tile, const FChunk& h, int lan
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<f4*>(tile + tgrp(16 * o + 4 * g + r, c)) = f4{h.a[o][0][r], h.a[o][1][r], h.a[o][2][r], h.a[o][3][r]};
+    for (int r = 0; r < 4; ++r) {
+      fvT v;
+#pragma unroll
+      for (int sidx = 0; sidx < FT; ++sidx) v[sidx] = h.a[o][sidx][r];
+      *reinterpret_cast<fvT*>(tile + tpos(16 * o + 4 * g + r, FT * c)) = v;
+    }
 }
 // d *= act'(z) with act(z) read back from its tile
 template <int ACT>
@@ -370,33 +416,42 @@ __device__ __forceinline__ void chunk_mul_grad_T(FChunk& d, const float* tile, i
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const f4 a = *reinterpret_cast<const f4*>(tile + tgrp(16 * o + 4 * g + r, c));
+      const fvT a = *reinterpret_cast<const fvT*>(tile + tpos(16 * o + 4 * g + r, FT * c));
 #pragma unroll
       for (int sidx = 0; sidx < FT; ++sidx) d.a[o][sidx][r] *= grad_from_act<ACT>(a[sidx]);
     }
 }
 // rows [row0, row0 + 64) of a row-major [Q][32] array -> T[32][position] (zero beyond Q); lane = row of the block
 __device__ __forceinline__ void stage_rows_T(const float* __restrict__ gsrc, int64_t row0, int64_t Q, float* tile, int lane) {
-  const int64_t row = row0 + lane;
-  const f4* src = reinterpret_cast<const f4*>(gsrc + row * F_LDX);
-  f4 v[F_LDX / 4];
+  constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;  // lanes per row, 16-byte pieces per lane
+  const int rl = lane % FR, part = lane / FR;
+  const int64_t row = row0 + rl;
+  const f4* src = reinterpret_cast<const f4*>(gsrc + row * F_LDX) + part * NV;
+  f4 v[NV];
 #pragma unroll
-  for (int k = 0; k < F_LDX / 4; ++k) v[k] = row < Q ? src[k] : f4{0.f, 0.f, 0.f, 0.f};
-  const int c = lane & 15, sidx = lane >> 4;
+  for (int k = 0; k < NV; ++k) v[k] = row < Q ? src[k] : f4{0.f, 0.f, 0.f, 0.f};
+  const int p = FT * (rl & 15) + (rl >> 4);  // position of this row: column rl & 15 of sample tile rl >> 4
 #pragma unroll
-  for (int k = 0; k < F_LDX / 4; ++k)
+  for (int k = 0; k < NV; ++k)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tile[tgrp(4 * k + e, c) + sidx] = v[k][e];
+    for (int e = 0; e < 4; ++e) tile[tpos(4 * (part * NV + k) + e, p)] = v[k][e];
 }
 // B operands (natural k order) of the four sample tiles from T[32][position]: input 4 k + (lane >> 4)
 __device__ __forceinline__ void load_bops_T(float (&b)[FT][8], const float* tile, int lane) {
   const int c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const f4 v = *reinterpret_cast<const f4*>(tile + tgrp(4 * k + g, c));
+    const fvT v = *reinterpret_cast<const fvT*>(tile + tpos(4 * k + g, FT * c));
 #pragma unroll
     for (int sidx = 0; sidx < FT; ++sidx) b[sidx][k] = v[sidx];
   }
+}
+// sum over all positions of row `row` of a T tile (bias gradients: d b = sum over the samples of dZ)
+__device__ __forceinline__ float row_sum_T(const float* tile, int row) {
+  f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int grp = 0; grp < TNG; ++grp) sacc = sacc + *reinterpret_cast<const f4*>(tile + row * TP + 4 * grp);
+  return (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
 }
 // acc[o][i] += sum over the 64 positions of A[16 o + .][p] * B[16 i + .][p]   (both T tiles)
 template <int NO, int NI>
@@ -405,12 +460,12 @@ __device__ __forceinline__ void wgrad_T(f4 (&acc)[NO][NI], const float* ta, cons
   // one 16-byte group (4 k-steps) of every operand tile at a time: NO + NI live operand registers x 4, and the
   // scheduler is kept from hoisting all sixteen k-steps' reads (the kernel sits at the 256 architectural registers)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < FT; ++j) {  // lane (unit u, q) owns positions q TP / 4 .. : FT groups of 4 k-steps
     f4 av[NO], bv[NI];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) av[o] = *reinterpret_cast<const f4*>(ta + tgrp(16 * o + u, 4 * q + j));
+    for (int o = 0; o < NO; ++o) av[o] = *reinterpret_cast<const f4*>(ta + tgrp(16 * o + u, FT * q + j));
 #pragma unroll
-    for (int i = 0; i < NI; ++i) bv[i] = *reinterpret_cast<const f4*>(tb + tgrp(16 * i + u, 4 * q + j));
+    for (int i = 0; i < NI; ++i) bv[i] = *reinterpret_cast<const f4*>(tb + tgrp(16 * i + u, FT * q + j));
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -427,12 +482,12 @@ __device__ __forceinline__ void wgrad_T(f4 (&acc)[NO][NI], const float* ta, cons
 //            dZ2 leaves as a raw register dump [block][tile][sample tile][lane] x 16 bytes (coalesced both ways)
 //   pass B   X -> A1 (layer 1 again: 10 % more matrix work);  dZ1 = (W2^T dZ2) * act'(Z1);  dW1 += dZ1^T X;  db1
 template <int ACT>
-__global__ __launch_bounds__(64) void mlp_bwd3a_kernel(const FusedArgs A) {
-  __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // X^T, then dOUT^T
+__global__ __launch_bounds__(64, 2) void mlp_bwd3a_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // dOUT^T
   __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1
   __shared__ __attribute__((aligned(16))) float tv[64 * TP];  // A2 -> dZ2
   const int lane = threadIdx.x;
-  const int64_t nblk = (A.Q + 63) / 64;
+  const int64_t nblk = (A.Q + FR - 1) / FR;
   f4 aW2[4][4], aW3[2][4];
 #pragma unroll
   for (int o = 0; o < 4; ++o)
@@ -442,38 +497,18 @@ __global__ __launch_bounds__(64) void mlp_bwd3a_kernel(const FusedArgs A) {
   for (int o = 0; o < 2; ++o)
 #pragma unroll
     for (int i = 0; i < 4; ++i) aW3[o][i] = f4{0.f, 0.f, 0.f, 0.f};
-  f4 pb2[4];
-#pragma unroll
-  for (int o = 0; o < 4; ++o) pb2[o] = f4{0.f, 0.f, 0.f, 0.f};
-  float pbo = 0.f;
+  float pb2 = 0.f, pbo = 0.f;  // bias gradients of unit `lane`: row sums of the dZ2 / dOUT^T tiles
   for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
-    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
-    fsync();
+    stage_rows_T(A.dout, rb * FR, A.Q, ts, lane);
     {
-      FChunk h1;
-      {
-        float bin[FT][8];
-        load_bops_T(bin, ts, lane);
-        chunk_set_bias(h1, A.bfr[0], 0, lane);
-        facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
-      }
-      fsync();  // X^T has been read by every lane: dOUT^T may overwrite it
-      stage_rows_T(A.dout, rb * 64, A.Q, ts, lane);
-      chunk_act_only<ACT>(h1);
-      chunk_to_T(tu, h1, lane);
-      FChunk h2;
-      chunk_set_bias(h2, A.bfr[1], 0, lane);
-      facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
-      chunk_act_only<ACT>(h2);
-      chunk_to_T(tv, h2, lane);
+      FChunk h;
+      chunk_undump(h, A.a1d, rb, lane);
+      chunk_to_T(tu, h, lane);  // A1
+      chunk_undump(h, A.a2d, rb, lane);
+      chunk_to_T(tv, h, lane);  // A2
     }
     fsync();
-    if (lane < 32) {
-      f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) sacc = sacc + *reinterpret_cast<const f4*>(ts + lane * TP + 4 * grp);
-      pbo += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
-    }
+    if (lane < 32) pbo += row_sum_T(ts, lane);
     wgrad_T<2, 4>(aW3, ts, tv, lane);  // dW3 += dOUT^T A2
     FChunk d2;
     chunk_zero(d2);
@@ -483,87 +518,68 @@ __global__ __launch_bounds__(64) void mlp_bwd3a_kernel(const FusedArgs A) {
       facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
     }
     chunk_mul_grad_T<ACT>(d2, tv, lane);
-    bias_partial(pb2, d2);
-    {
-      f4* dst = reinterpret_cast<f4*>(A.dz2) + (size_t)rb * (16 * 64) + lane;
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int sidx = 0; sidx < FT; ++sidx) dst[(o * FT + sidx) * 64] = d2.a[o][sidx];
-    }
+    chunk_dump(A.dz2, rb, d2, lane);
     fsync();
     chunk_to_T(tv, d2, lane);  // dZ2 (A2 is consumed)
     fsync();
+    pb2 += row_sum_T(tv, lane);
     wgrad_T<4, 4>(aW2, tv, tu, lane);  // dW2 += dZ2^T A1
     fsync();
   }
   float* slab = A.slab + (size_t)blockIdx.x * A.P;
   wgrad_flush<2, 4>(aW3, slab + A.poff[4], A.nout, A.h2, 0, 0, lane);
   wgrad_flush<4, 4>(aW2, slab + A.poff[2], A.h2, A.h1, 0, 0, lane);
-  bias_flush(pb2, slab + A.poff[3], A.h2, 0, lane);
+  if (lane < A.h2) slab[A.poff[3] + lane] = pb2;
   if (lane < A.nout) slab[A.poff[5] + lane] = pbo;
 }
 
 template <int ACT>
-__global__ __launch_bounds__(64) void mlp_bwd3b_kernel(const FusedArgs A) {
+__global__ __launch_bounds__(64, 2) void mlp_bwd3b_kernel(const FusedArgs A) {
   __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // X^T
   __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1 -> dZ1
   const int lane = threadIdx.x;
-  const int64_t nblk = (A.Q + 63) / 64;
+  const int64_t nblk = (A.Q + FR - 1) / FR;
   f4 aW1[4][2];
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
-  f4 pb1[4];
-#pragma unroll
-  for (int o = 0; o < 4; ++o) pb1[o] = f4{0.f, 0.f, 0.f, 0.f};
+  float pb1 = 0.f;
   for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
-    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
+    stage_rows_T(A.x, rb * FR, A.Q, ts, lane);
     FChunk d2;
-    {
-      const f4* src = reinterpret_cast<const f4*>(A.dz2) + (size_t)rb * (16 * 64) + lane;
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int sidx = 0; sidx < FT; ++sidx) d2.a[o][sidx] = src[(o * FT + sidx) * 64];
-    }
-    fsync();
+    chunk_undump(d2, A.dz2, rb, lane);
     {
       FChunk h1;
-      float bin[FT][8];
-      load_bops_T(bin, ts, lane);
-      chunk_set_bias(h1, A.bfr[0], 0, lane);
-      facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
-      chunk_act_only<ACT>(h1);
-      chunk_to_T(tu, h1, lane);
+      chunk_undump(h1, A.a1d, rb, lane);
+      chunk_to_T(tu, h1, lane);  // A1
     }
     FChunk d1;
     chunk_zero(d1);
     facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
     fsync();
     chunk_mul_grad_T<ACT>(d1, tu, lane);
-    bias_partial(pb1, d1);
     fsync();
     chunk_to_T(tu, d1, lane);  // dZ1 (A1 is consumed)
     fsync();
+    pb1 += row_sum_T(tu, lane);
     wgrad_T<4, 2>(aW1, tu, ts, lane);  // dW1 += dZ1^T X
     fsync();
   }
   float* slab = A.slab + (size_t)blockIdx.x * A.P;
   wgrad_flush<4, 2>(aW1, slab + A.poff[0], A.h1, A.in, 0, 0, lane);
-  bias_flush(pb1, slab + A.poff[1], A.h1, 0, lane);
+  if (lane < A.h1) slab[A.poff[1] + lane] = pb1;
 }
 
 // Two-layer networks in -> H1 -> out with any H1: wave w handles hidden chunk w % c1 (64 units) over the row blocks
 // w / c1, w / c1 + G / c1, ...
 template <int ACT>
-__global__ __launch_bounds__(64) void mlp_bwd2_kernel(const FusedArgs A) {
+__global__ __launch_bounds__(64, 2) void mlp_bwd2_kernel(const FusedArgs A) {
   __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // X^T, then dOUT^T, then X^T again
   __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1
   __shared__ __attribute__((aligned(16))) float tv[64 * TP];  // dZ1
   const int lane = threadIdx.x;
-  const int64_t nblk = (A.Q + 63) / 64;
+  const int64_t nblk = (A.Q + FR - 1) / FR;
   const int nchunk = A.c1;
   const int chunk = blockIdx.x % nchunk;
   const int64_t rb0 = blockIdx.x / nchunk, rbstep = gridDim.x / nchunk;
@@ -577,12 +593,9 @@ __global__ __launch_bounds__(64) void mlp_bwd2_kernel(const FusedArgs A) {
   for (int o = 0; o < 2; ++o)
 #pragma unroll
     for (int i = 0; i < 4; ++i) aWo[o][i] = f4{0.f, 0.f, 0.f, 0.f};
-  f4 pb1[4];
-#pragma unroll
-  for (int o = 0; o < 4; ++o) pb1[o] = f4{0.f, 0.f, 0.f, 0.f};
-  float pbo = 0.f;
+  float pb1 = 0.f, pbo = 0.f;
   for (int64_t rb = rb0; rb < nblk; rb += rbstep) {
-    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
+    stage_rows_T(A.x, rb * FR, A.Q, ts, lane);
     fsync();
     {
       FChunk h1;
@@ -591,17 +604,12 @@ __global__ __launch_bounds__(64) void mlp_bwd2_kernel(const FusedArgs A) {
       chunk_set_bias(h1, A.bfr[0], 4 * chunk, lane);
       facc<4, 8>(h1.a, A.wf[0], 8, 4 * chunk, 0, lane, [&](int s, int k) { return bin[s][k]; });
       fsync();
-      stage_rows_T(A.dout, rb * 64, A.Q, ts, lane);
+      stage_rows_T(A.dout, rb * FR, A.Q, ts, lane);
       chunk_act_only<ACT>(h1);
       chunk_to_T(tu, h1, lane);  // A1 chunk
     }
     fsync();
-    if (chunk == 0 && lane < 32) {
-      f4 sacc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int grp = 0; grp < 16; ++grp) sacc = sacc + *reinterpret_cast<const f4*>(ts + lane * TP + 4 * grp);
-      pbo += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
-    }
+    if (chunk == 0 && lane < 32) pbo += row_sum_T(ts, lane);
     wgrad_T<2, 4>(aWo, ts, tu, lane);  // dW2[:, chunk] += dOUT^T A1
     // dZ1 = (W2^T[chunk] dOUT) * act'(Z1)
     FChunk d1;
@@ -612,18 +620,18 @@ __global__ __launch_bounds__(64) void mlp_bwd2_kernel(const FusedArgs A) {
       facc<4, 8>(d1.a, A.wt[1], A.kst[1], 4 * chunk, 0, lane, [&](int s, int k) { return bd[s][k]; });
     }
     chunk_mul_grad_T<ACT>(d1, tu, lane);
-    bias_partial(pb1, d1);
     fsync();
-    stage_rows_T(A.x, rb * 64, A.Q, ts, lane);
+    stage_rows_T(A.x, rb * FR, A.Q, ts, lane);
     chunk_to_T(tv, d1, lane);
     fsync();
+    pb1 += row_sum_T(tv, lane);
     wgrad_T<4, 2>(aW1, tv, ts, lane);  // dW1[chunk] += dZ1^T X
     fsync();
   }
   float* slab = A.slab + (size_t)rb0 * A.P;  // one slab per row-block stream; its chunks write disjoint parts
   wgrad_flush<2, 4>(aWo, slab + A.poff[2], A.nout, A.h1, 0, 64 * chunk, lane);
   wgrad_flush<4, 2>(aW1, slab + A.poff[0], A.h1, A.in, 64 * chunk, 0, lane);
-  bias_flush(pb1, slab + A.poff[1], A.h1, 64 * chunk, lane);
+  if (64 * chunk + lane < A.h1) slab[A.poff[1] + 64 * chunk + lane] = pb1;
   if (chunk == 0 && lane < A.nout) slab[A.poff[3] + lane] = pbo;
 }
 
@@ -676,10 +684,10 @@ static size_t fused_frag_floats(int n_layers, const int32_t* dims) {
 }
 size_t fused_ws_bytes(int n_layers, const int32_t* dims, int64_t Q) {
   size_t n = ((fused_frag_floats(n_layers, dims) + 63) & ~size_t(63)) * sizeof(float) + 256;
-  if (n_layers == 3) n += (size_t)((Q + 63) / 64) * 16 * 64 * 16;  // dZ2 between the two backward passes
+  if (n_layers == 3) n += 3 * (size_t)((Q + FR - 1) / FR) * 4 * FT * 64 * 16;  // A1, A2 (forward -> backward), dZ2 (pass A -> B)
   size_t P = 0;
   for (int k = 0; k < n_layers; ++k) P += (size_t)dims[k] * dims[k + 1] + dims[k + 1];
-  n += 1024 * ((P + 63) & ~size_t(63)) * sizeof(float);  // slabs of partial weight gradients
+  n += (size_t)F_MAXW * ((P + 63) & ~size_t(63)) * sizeof(float);  // slabs of partial weight gradients
   return n;
 }
 
@@ -737,8 +745,13 @@ int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_
   A.Q = Q; A.x = x; A.out = out;
   int rc = fused_pack(A, n_layers, dims, W, b, static_cast<float*>(ws), true, s);
   if (rc) return rc;
-  const int64_t nblk = (Q + 63) / 64;
-  const int grid = (int)(nblk < 2048 ? nblk : 2048);
+  const int64_t nblk = (Q + FR - 1) / FR;
+  const int grid = (int)(nblk < 4096 ? nblk : 4096);
+  if (n_layers == 3) {  // hidden activations stay in the workspace for the backward passes (same layout there)
+    float* wsf = static_cast<float*>(ws) + ((fused_frag_floats(n_layers, dims) + 63) & ~size_t(63));
+    A.a1d = wsf;
+    A.a2d = wsf + (size_t)nblk * 4 * FT * 64 * 4;
+  }
   launch_by_act(acts[0], [&](auto act) {
     hipLaunchKernelGGL((mlp_fwd_fused_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
   });
@@ -754,17 +767,18 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
   for (int k = 0; k < n_layers; ++k) { A.dW[k] = dW[k]; A.db[k] = db[k]; }
   int rc = fused_pack(A, n_layers, dims, W, nullptr, static_cast<float*>(ws), false, s);
   if (rc) return rc;
-  const int64_t nblk = (Q + 63) / 64;
+  const int64_t nblk = (Q + FR - 1) / FR;
   const int nchunk = n_layers == 2 ? A.c1 : 1;
   int64_t waves = nblk * nchunk;
-  if (waves > 1024) waves = 1024 / nchunk * nchunk;  // 4 workgroups of 40 KB LDS per CU: one wave per SIMD
+  if (waves > F_MAXW) waves = F_MAXW / nchunk * nchunk;  // as many workgroups as the LDS of the chip holds
   if (waves < nchunk) waves = nchunk;
   const int grid = (int)waves;
-  // workspace behind the packed fragments: [dZ2 between the two passes of a three-layer network] [gradient slabs]
+  // workspace behind the packed fragments: [A1, A2, dZ2 images of a three-layer network] [gradient slabs]
   float* wsf = static_cast<float*>(ws) + ((fused_frag_floats(n_layers, dims) + 63) & ~size_t(63));
   if (n_layers == 3) {
-    A.dz2 = wsf;
-    wsf += (size_t)nblk * 16 * 64 * 4;
+    const size_t img = (size_t)nblk * 4 * FT * 64 * 4;
+    A.a1d = wsf; A.a2d = wsf + img; A.dz2 = wsf + 2 * img;
+    wsf += 3 * img;
   }
   int P = 0;
   for (int k = 0; k < n_layers; ++k) {
@@ -776,7 +790,7 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
   A.P = (P + 63) & ~63;
   A.slab = wsf;
   if (n_layers == 3) {
-    const int grid3 = (int)(nblk < 1024 ? nblk : 1024);
+    const int grid3 = (int)(nblk < F_MAXW ? nblk : F_MAXW);
     A.nslab = grid3;
     launch_by_act(acts[0], [&](auto act) {
       hipLaunchKernelGGL((mlp_bwd3a_kernel<decltype(act)::value>), dim3(grid3), dim3(64), 0, s, A);
