@@ -184,12 +184,12 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
       int rcp = ensure_pred(h, B);
       if (rcp) return rcp;
       sa.pred_io = static_cast<double*>(h->pred_buf);
-      sa.pred_load = h->pred_valid_B == B;
+      sa.pred_load = h->pred_valid_B == B && h->pred_valid_W == 1;
     }
     const int rc = launch_sim_persistent<T>(h, scheme, use_nn, sa, s);
     if (rc != 1) {
       h->last_sim_path = 2;
-      if (rc == KR_OK && sa.pred_io) h->pred_valid_B = B;
+      if (rc == KR_OK && sa.pred_io) { h->pred_valid_B = B; h->pred_valid_W = 1; }
       return rc;
     }
   }
@@ -197,15 +197,17 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
   // one launch per step: the multiple-shooting kernel carries its start-value predictor from launch to launch
   // through an image in HBM (12 KB per rod; skipped for batches that would need more than 1 GB of it)
   double* pred = nullptr;
+  const int wpr = step_waves_per_rod<T>(h, scheme, use_nn, B, 0);  // (one image per wavefront of a rod)
+  const int img_w = wpr ? wpr : 1;
   if (h->predictor > 2 && h->ms_mode != 0 && (h->ms_mode == 1 || B <= (int64_t)h->ms_batch_limit)) {
-    const size_t need = (size_t)B * KR_PRED_IMG_DOUBLES * sizeof(double);
+    const size_t need = (size_t)B * img_w * KR_PRED_IMG_DOUBLES * sizeof(double);
     if (need <= ((size_t)1 << 30)) {
-      int rcp = ensure_pred(h, B);
+      int rcp = ensure_pred(h, B * img_w);
       if (rcp) return rcp;
       pred = static_cast<double*>(h->pred_buf);
     }
   }
-  const bool resume = pred && h->keep_predictor && h->pred_valid_B == B;
+  const bool resume = pred && h->keep_predictor && h->pred_valid_B == B && h->pred_valid_W == img_w;
   for (int64_t t = 0; t < T_steps; ++t) {
     // knode.py:65-66,76-77: before the first step y_prev = y (unless the caller hands over the state before)
     const int64_t ic = ring ? t % 3 : t;
@@ -228,6 +230,7 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
   }
   // the image is current only if the multiple-shooting kernel took the steps (launch_step decides)
   if (pred) h->pred_valid_B = (T_steps > 0 && h->last_sim_path == 1) ? B : (T_steps > 0 ? 0 : h->pred_valid_B);
+  if (pred && T_steps > 0) h->pred_valid_W = img_w;
   return KR_OK;
 }
 
@@ -348,6 +351,10 @@ int kr_create(const kr_params* p, int device, kr_handle** out) {
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
     h->lds_limit = lds;
   if (const char* e = std::getenv("KR_MS_MODE")) h->ms_mode = std::atoi(e);
+  if (const char* e = std::getenv("KR_WAVES_PER_ROD")) {
+    const int w = std::atoi(e);
+    if (w == 0 || w == 1 || w == 2 || w == 4) h->waves_per_rod = w;
+  }
   if (const char* e = std::getenv("KR_PREDICTOR")) h->predictor = std::atoi(e);
   if (const char* e = std::getenv("KR_PERSISTENT")) h->persistent = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_MFMA_MLP")) h->mfma_mlp = std::atoi(e) ? 1 : 0;
@@ -368,6 +375,9 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
     h->ms_batch_limit = value;
   } else if (n == "persistent") {
     h->persistent = value ? 1 : 0;
+  } else if (n == "waves_per_rod") {
+    if (value != 0 && value != 1 && value != 2 && value != 4) { set_error("waves_per_rod must be 0 (auto), 1, 2 or 4"); return KR_E_ARG; }
+    h->waves_per_rod = value;
   } else if (n == "mlp_grad_accumulate") {
     h->grad_accumulate = value ? 1 : 0;
   } else if (n == "keep_predictor") {
@@ -401,6 +411,8 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   else if (n == "fused_mlp") *value = h->fused_mlp;
   else if (n == "predictor") *value = h->predictor;
   else if (n == "last_sim_path") *value = h->last_sim_path;
+  else if (n == "waves_per_rod") *value = h->waves_per_rod;
+  else if (n == "last_waves_per_rod") *value = h->last_waves_per_rod;
   else {
     set_error("unknown option " + n);
     return KR_E_ARG;

@@ -69,6 +69,7 @@ struct kr_handle {
   int grad_accumulate = 0;    // kr_mlp_backward / kr_loss_rows_fwd_bwd add to dW, db, loss instead of zeroing them first
   int keep_predictor = 0;     // kr_simulate_batch resumes from / leaves behind the predictor image (option)
   int64_t pred_valid_B = 0;   // batch size the image in pred_buf was written for (0: none)
+  int pred_valid_W = 1;       // ... and the wavefronts per rod of the kernel that wrote it
   size_t ws_bytes = 0;
   int lds_limit = 160 * 1024;
   int ms_mode = -1;          // multiple-shooting step kernel: -1 auto (by batch size), 0 off, 1 forced
@@ -78,6 +79,8 @@ struct kr_handle {
   int predictor = 8;         // highest extrapolation order kr_simulate_batch may use (per-step launches: <= 2)
   int last_sim_path = 0;     // what the last kr_simulate_batch did: 0 one single-shooting launch per step,
                              // 1 one multiple-shooting launch per step, 2 one persistent launch for all steps
+  int waves_per_rod = 0;     // per-step launches: wavefronts that share a rod (kr_msw_impl.hpp): 0 auto, 1, 2 or 4
+  int last_waves_per_rod = 1;  // what the last step launch used
   void* dbg = nullptr;       // diagnostic cycle-counter buffer (kr_debug_buffer)
   int fused_mlp = 1;         // training: fused MFMA forward/backward kernels (kr_mlp_fused.hip) when the shape allows
   int mfma_mlp = 1;          // evaluate the in-sweep MLP on the matrix cores when its shape allows
@@ -148,6 +151,9 @@ struct StepArgs {
 };
 template <typename T>
 int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s);
+// wavefronts per rod the several-wavefront step kernel (kr_msw_impl.hpp) would use for this call; 0: not that kernel
+template <typename T>
+int step_waves_per_rod(kr_handle* h, int scheme, int use_nn, int64_t B, int mode);
 
 // persistent multi-step form (kr_ms_impl.hpp)
 template <typename T>

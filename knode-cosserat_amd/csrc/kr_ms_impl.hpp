@@ -1524,7 +1524,13 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
   set_error("unknown scheme");
   return KR_E_ARG;
 }
+}  // namespace kr
+
+#include "kr_msw_impl.hpp"  // several wavefronts per rod (uses everything above)
+
+namespace kr {
 template int launch_sim_persistent<KR_SIM_T>(kr_handle*, int, int, const SimArgs<KR_SIM_T>&, hipStream_t);
+template int step_waves_per_rod<KR_SIM_T>(kr_handle*, int, int, int64_t, int);
 
 KR_INST(KR_SIM_T)
 

@@ -1,0 +1,801 @@
+// kr_msw_impl.hpp - multiple shooting with SEVERAL wavefronts per rod (one time step per launch).
+//
+// kr_ms_impl.hpp gives a rod one wavefront and P = 4 sub-intervals; the dependent chain of a sweep is then
+// (N - 1) / 4 grid points long and a batch keeps B of the chip's 1024 SIMDs busy.  Long rods in small batches
+// (BASELINE cfg5: N = 400, B = 512) leave half the chip idle behind a 100-point chain.  Here a rod owns a workgroup
+// of W wavefronts: wavefront 0 integrates sub-intervals 0..3 exactly as before (7 + 3 x 17 lanes), every further
+// wavefront three more (3 x 17 lanes), P = 4 + 3 (W - 1) sub-intervals in all, chain length (N - 1) / P.
+//
+// The nonlinear system is the same (unknowns G, Y_1 .. Y_{P-1}; continuity E_g(Y_g) = Y_{g+1}; tip condition on the
+// last interval), Newton with forward-difference columns, condensed onto the 6 base unknowns:
+//   * wavefront 0 chains  X_{g+1} = [c_g | 0] + A_g X_g  (X_g = [a_g | M_g], 16 x 7: dY_g = X_g [1; dG]) over its
+//     four intervals, as kr_ms_impl.hpp does;
+//   * wavefront w >= 1 does not know dY at its first interval yet: it composes its three intervals into one affine
+//     map  dY_out = a + B dY_in  (L_k = [a_k | B_k], 16 x 17:  L_0 = [c | A],  L_{k+1} = [c | 0] + A L_k) - all
+//     wavefronts in parallel;
+//   * then the boundary blocks are passed down the rod,  X^(w+1) = [a^w | 0] + B^w X^(w)  (one 16x16 by 16x7 product
+//     per wavefront, serial, workgroup barriers in between); the last one yields the 6 x 6 system for dG;
+//   * back-substitution: every wavefront forms dY at its first interval from X^(w) and dG, its inner ones from L_k.
+// The p rows (no equation reads p) are accumulated afterwards from all intervals, like in the one-wavefront kernel.
+// Stopping rule, storing sweep prediction, start-value predictor (one MsPred per wavefront over its own unknowns, the
+// decisions reduced over the workgroup) are those of kr_ms_impl.hpp; the chord check is not used here.
+//
+// History records are the 12 raw BDF2 terms only (q_h w_h v_h u_h); av / au are re-derived per evaluation (6 FMAs), so
+// that two N = 400 rods fit the LDS of a CU in fp64.  Euler sweeps, MLP off (what long rods in small batches run).
+#pragma once
+// (included by kr_ms_impl.hpp, after its definitions)
+
+namespace kr {
+
+constexpr int HS_LEAN = 12;
+template <int W>
+struct MswGeo {
+  static constexpr int P = 4 + 3 * (W - 1);
+};
+constexpr int MSW_LT_LD = 20;  // row pitch of the 16 x 17 local-map tiles
+
+struct MswRole {
+  int w, iv, ivl, col, s_i, len_i, sbase, comp, l0own, g0, K;
+  bool idle;
+};
+template <int W>
+__device__ __forceinline__ MswRole msw_role(int wave, int lane, int N) {
+  constexpr int P = MswGeo<W>::P;
+  MswRole R;
+  R.w = wave;
+  if (wave == 0) {
+    R.idle = lane >= 58;
+    if (lane < 7) { R.ivl = 0; R.col = lane; }
+    else if (!R.idle) { R.ivl = 1 + (lane - 7) / 17; R.col = (lane - 7) % 17; }
+    else { R.ivl = 0; R.col = 0; }
+    R.g0 = 0; R.K = 4;
+    R.l0own = R.ivl == 0 ? 0 : 7 + 17 * (R.ivl - 1);
+  } else {
+    R.idle = lane >= 51;
+    R.ivl = R.idle ? 0 : lane / 17;
+    R.col = R.idle ? 0 : lane % 17;
+    R.g0 = 4 + 3 * (wave - 1); R.K = 3;
+    R.l0own = 17 * R.ivl;
+  }
+  R.iv = R.g0 + R.ivl;
+  const int nseg = N - 1;
+  R.sbase = nseg / P;
+  const int srem = nseg % P;
+  R.s_i = R.iv * R.sbase + (R.iv < srem ? R.iv : srem);
+  R.len_i = R.sbase + (R.iv < srem ? 1 : 0);
+  R.comp = R.col == 0 ? -1 : (R.iv == 0 ? 6 + R.col : 2 + R.col);
+  return R;
+}
+__device__ __forceinline__ int msw_l0(int wave, int k) { return wave == 0 ? (k == 0 ? 0 : 7 + 17 * (k - 1)) : 17 * k; }
+__device__ __forceinline__ int msw_start(int g, int N, int P) {
+  const int nseg = N - 1, sbase = nseg / P, srem = nseg % P;
+  return g * sbase + (g < srem ? g : srem);
+}
+
+// LDS of one rod (elements of T; every array starts at a multiple of 4 elements)
+template <typename T, int W>
+struct MswLds {
+  T* hist;   // [N][HS_LEAN]
+  T* Xs;     // [P][19] unknowns
+  T* cold;   // [CD_SIZE]
+  T* Tm;     // [6][8]
+  T* Xbd;    // [W][19][8] boundary blocks X^(w) (rows 3..18), w = 1 .. W-1
+  T* dY;     // [P][19] updates of all unknowns
+  T* sp;     // [P][4] p-row terms of every interval
+  T* red;    // [W][32] reduction scratch
+  T* Es;     // [W][64][19]
+  T* Lt;     // [W][2][19][MSW_LT_LD]
+};
+template <typename T, int W>
+__host__ __device__ inline size_t msw_lds_elems(int N) {
+  constexpr int P = MswGeo<W>::P;
+  auto r4 = [](size_t n) { return (n + 3) & ~size_t(3); };
+  return r4((size_t)N * HS_LEAN) + r4(P * 19) + r4(CD_SIZE) + 48 + r4(W * 19 * 8) + r4(P * 19) + r4(P * 4) + W * 32 +
+         (size_t)W * r4(64 * 19) + (size_t)W * 2 * 19 * MSW_LT_LD;
+}
+template <typename T, int W>
+__device__ __forceinline__ MswLds<T, W> msw_carve(T* smem, int N) {
+  constexpr int P = MswGeo<W>::P;
+  auto r4 = [](size_t n) { return (n + 3) & ~size_t(3); };
+  MswLds<T, W> L;
+  L.hist = smem;
+  L.Xs = L.hist + r4((size_t)N * HS_LEAN);
+  L.cold = L.Xs + r4(P * 19);
+  L.Tm = L.cold + r4(CD_SIZE);
+  L.Xbd = L.Tm + 48;
+  L.dY = L.Xbd + r4(W * 19 * 8);
+  L.sp = L.dY + r4(P * 19);
+  L.red = L.sp + r4(P * 4);
+  L.Es = L.red + W * 32;
+  L.Lt = L.Es + (size_t)W * r4(64 * 19);
+  return L;
+}
+
+// av, au of a grid point from its raw history (see RodHist)
+template <typename T, bool DIAG>
+__device__ __forceinline__ RodHist<T> hist_lean(const RodConst<T>& P, const T (&hv)[HS_LEAN]) {
+  RodHist<T> h;
+  h.qh = {hv[0], hv[1], hv[2]};
+  h.wh = {hv[3], hv[4], hv[5]};
+  h.vh = {hv[6], hv[7], hv[8]};
+  h.uh = {hv[9], hv[10], hv[11]};
+  if constexpr (DIAG) {
+    h.av = {P.Ksei[0] * (P.Kse_vstar[0] - P.Bse[0] * h.vh.x), P.Ksei[4] * (P.Kse_vstar[1] - P.Bse[4] * h.vh.y),
+            P.Ksei[8] * (P.Kse_vstar[2] - P.Bse[8] * h.vh.z)};
+    h.au = {-P.Kbti[0] * (P.Bbt[0] * h.uh.x), -P.Kbti[4] * (P.Bbt[4] * h.uh.y), -P.Kbti[8] * (P.Bbt[8] * h.uh.z)};
+  } else {
+    hist_derive(P, h);
+  }
+  return h;
+}
+
+// workgroup-wide reductions (W wavefronts, every one calls; scratch: W slots of T per call site)
+template <int W>
+__device__ __forceinline__ float msw_max(float v, float* red, int wave, int lane) {
+  v = wave_max_nonneg(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float m = red[0];
+#pragma unroll
+  for (int k = 1; k < W; ++k) m = fmaxf(m, red[k]);
+  __syncthreads();
+  return m;
+}
+template <int W>
+__device__ __forceinline__ double msw_sum(double v, double* red, int wave, int lane) {
+  v = wave_sum_f64(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int k = 1; k < W; ++k) s += red[k];
+  __syncthreads();
+  return s;
+}
+
+// ---- predictor of one wavefront's unknowns (NE = K x 19 entries of Xs starting at interval g0) -------------------
+template <typename T>
+__device__ __forceinline__ void mswp_init(MsPred<T>& Q, int lane, int ne, int g0, int N, int P, const T* s0, const T* sp,
+                                          bool has_prev, int predictor) {
+#pragma unroll
+  for (int q = 0; q < MS_EPL; ++q) {
+    const int e = lane + q * WAVE;
+    const int i = e < ne ? e / 19 : 0, r = e < ne ? e - i * 19 : 0;
+    const size_t off = (size_t)msw_start(g0 + i, N, P) * KR_SLOTS + ms_slot_of_yrow(r);
+    Q.Hx[q][0] = s0[off];
+#pragma unroll
+    for (int k = 1; k < MS_HLEV; ++k) Q.Hx[q][k] = sp[off];
+  }
+  Q.lpa[0] = Q.lpa[1] = Q.lpa[2] = 1.0;
+  Q.lp_have = Q.lp_good = false;
+  Q.lp_age = 0;
+  Q.avail = has_prev ? 1 : 0;
+  Q.next_order = Q.avail < predictor ? Q.avail : predictor;
+  if (Q.next_order >= MS_HLEV) Q.next_order = MS_HLEV - 1;
+  Q.kappa = T(0);
+}
+template <typename T>
+__device__ __forceinline__ void mswp_guess(const MsPred<T>& Q, int order, int lane, int ne, bool first, const T* cold, T* Xl) {
+#pragma unroll
+  for (int q = 0; q < MS_EPL; ++q) {
+    const int e = lane + q * WAVE;
+    if (e < ne) {
+      const int i = e / 19, r = e - i * 19;
+      T g;
+      if (order == MS_ORDER_LP) {
+        const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+        g = (T)(Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2));
+      } else {
+        g = extrapolate_n<T>(order, Q.Hx[q]);
+      }
+      if (first && i == 0) {
+        T bc;
+        if (ms_base_bc(cold, r, bc)) g = bc;
+      }
+      Xl[e] = g;
+    }
+  }
+}
+// ms_pred_update with its decisions reduced over the W wavefronts of the rod
+template <typename T, int W>
+__device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status, int predictor, int lane, int wave, int ne,
+                                            const T* Xl, T* redT) {
+  float* redf = reinterpret_cast<float*>(redT);
+  double* redd = reinterpret_cast<double*>(redT);  // (W * 32 elements of T >= W doubles)
+  const bool poly_eval = !(order == MS_ORDER_LP && Q.lp_good);
+  float err[MS_HLEV];
+#pragma unroll
+  for (int p = 0; p < MS_HLEV; ++p) err[p] = 0.f;
+  if (poly_eval) {
+#pragma unroll
+    for (int q = 0; q < MS_EPL; ++q) {
+      const int e = lane + q * WAVE;
+      if (e < ne) {
+        const T x = Xl[e];
+#pragma unroll
+        for (int p = 0; p < MS_HLEV; ++p) err[p] = fmaxf(err[p], update_ratio(x - extrapolate_n<T>(p, Q.Hx[q]), x));
+      }
+    }
+  }
+  float err_lp = 0.f;
+  if (Q.lp_have) {
+#pragma unroll
+    for (int q = 0; q < MS_EPL; ++q) {
+      const int e = lane + q * WAVE;
+      if (e < ne) {
+        const double x = (double)Xl[e];
+        const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+        err_lp = fmaxf(err_lp, update_ratio(x - (Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2)), x));
+      }
+    }
+  }
+  const float em_lp = msw_max<W>(err_lp, redf, wave, lane);
+  const bool lp_tested = Q.lp_have;
+  const bool keep_fit = lp_tested && em_lp < 1.0e-3f && Q.lp_age < 3 && status == KR_ST_CONVERGED;
+  Q.lp_age = keep_fit ? Q.lp_age + 1 : 0;
+  Q.lp_have = keep_fit;
+  if (!keep_fit && predictor >= MS_ORDER_LP && Q.avail >= 2 && status == KR_ST_CONVERGED) {
+    double Sn[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < MS_EPL; ++q) {
+      const int e = lane + q * WAVE;
+      if (e < ne) {
+        const double x = (double)Xl[e];
+        const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+        const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
+        const double w0 = h0 * w, w1 = (h0 - h1) * w, w2 = (h0 - 2.0 * h1 + h2) * w, xw = x * w;
+        Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
+        Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Sn[k] = msw_sum<W>(Sn[k], redd, wave, lane);
+    const double lam = 1e-12;
+    double a6[3][4] = {{Sn[0] * (1 + lam), Sn[1], Sn[2], Sn[6] + lam * Sn[0]},
+                       {Sn[1], Sn[3] * (1 + lam), Sn[4], Sn[7] + lam * Sn[3]},
+                       {Sn[2], Sn[4], Sn[5] * (1 + lam), Sn[8] + lam * Sn[5]}};
+    const double i0 = fast_rcp(a6[0][0]);
+    const double f1 = a6[1][0] * i0, f2 = a6[2][0] * i0;
+#pragma unroll
+    for (int c = 1; c < 4; ++c) { a6[1][c] -= f1 * a6[0][c]; a6[2][c] -= f2 * a6[0][c]; }
+    const double i1 = fast_rcp(a6[1][1]);
+    const double f3 = a6[2][1] * i1;
+    a6[2][2] -= f3 * a6[1][2]; a6[2][3] -= f3 * a6[1][3];
+    const double x2 = a6[2][3] * fast_rcp(a6[2][2]);
+    const double x1 = (a6[1][3] - a6[1][2] * x2) * i1;
+    const double x0 = (a6[0][3] - a6[0][1] * x1 - a6[0][2] * x2) * i0;
+    if (isfinite(x0) && isfinite(x1) && isfinite(x2) && fabs(x0) < 4.0 && fabs(x1) < 16.0 && fabs(x2) < 64.0) {
+      Q.lpa[0] = x0; Q.lpa[1] = x1; Q.lpa[2] = x2;
+      Q.lp_have = true;
+    }
+  }
+  const int pmax = Q.avail < predictor ? Q.avail : (predictor < MS_HLEV ? predictor : MS_HLEV - 1);
+  float em[MS_HLEV];
+#pragma unroll
+  for (int p = 0; p < MS_HLEV; ++p) em[p] = poly_eval ? msw_max<W>(err[p], redf, wave, lane) : 3.0e38f;
+  int nxt = 0;
+  float eb = em[0];
+#pragma unroll
+  for (int p = 1; p < MS_HLEV; ++p)
+    if (p <= pmax && p <= order + 2 && em[p] < eb) { eb = em[p]; nxt = p; }
+  if (nxt == Q.avail && Q.avail + 1 < MS_HLEV && Q.avail + 1 <= predictor && nxt >= order) nxt = Q.avail + 1;
+  if (!poly_eval) nxt = pmax;
+  Q.next_order = nxt;
+  Q.lp_good = lp_tested && Q.lp_have && em_lp < 1.0e-3f;
+  if (lp_tested && Q.lp_have && (em_lp < eb || Q.lp_good)) Q.next_order = MS_ORDER_LP;
+  if (status != KR_ST_CONVERGED) {
+    Q.next_order = 0;
+    Q.avail = -1;
+  }
+#pragma unroll
+  for (int q = 0; q < MS_EPL; ++q) {
+    const int e = lane + q * WAVE;
+#pragma unroll
+    for (int k = MS_HLEV - 1; k > 0; --k) Q.Hx[q][k] = Q.Hx[q][k - 1];
+    if (e < ne) Q.Hx[q][0] = Xl[e];
+  }
+  if (Q.avail < MS_HLEV - 1) ++Q.avail;
+}
+
+// ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
+template <typename T, bool DIAG, int W>
+__device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
+                                          V3<T> fconst, MsSolveArgs<T>& S, int& it) {
+  constexpr int P = MswGeo<W>::P;
+  const int N = Pc.N;
+  const int wave = R.w;
+  T* Xs = L.Xs;
+  T* Es = L.Es + (size_t)wave * ((64 * 19 + 3) & ~3);
+  T* Lt = L.Lt + (size_t)wave * 2 * 19 * MSW_LT_LD;
+  float* redf = reinterpret_cast<float*>(L.red);
+  const int iv = R.iv, col = R.col;
+  const bool idle = R.idle;
+  const int kp = lane & 3;
+  const int r = 3 + (lane >> 2);
+  const bool last_wave = wave == W - 1;
+  bool storing = false, flush = false;
+  int status = KR_ST_MAXIT;
+  it = 0;
+  T dn_prev = T(-1);
+  const T kappa_in = S.kappa;
+  bool below = false;
+
+  while (true) {
+    // ---- start state of this lane, forward-difference step of its column -------------------------------
+    T yr[19];
+#pragma unroll
+    for (int q = 0; q < 19; ++q) yr[q] = Xs[iv * 19 + q];
+    const T hstep = col > 0 ? S.fd_eps * fmax(fabs(Xs[iv * 19 + (R.comp > 0 ? R.comp : 3)]), T(1)) : T(1);
+#pragma unroll
+    for (int q = 3; q < 19; ++q) yr[q] += q == R.comp ? hstep : T(0);
+    RodState<T> y = rows_to_state(yr);
+    const bool st = (storing || flush) && col == 0 && !idle;
+
+    // ---- sweep over this lane's sub-interval (explicit Euler, cosserat_ode.py:198-201) ------------------
+    T hv[HS_LEAN];
+    load_hist_vec<T, HS_LEAN>(L.hist + (size_t)R.s_i * HS_LEAN, hv);
+    auto point = [&](auto store_tag, int j) __attribute__((always_inline)) {
+      constexpr bool STORE = decltype(store_tag)::value;
+      RodState<T> k1;
+      V3<T> v, u;
+      ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
+      if constexpr (STORE) {
+        if (st) {
+          T rec[KR_SLOTS];
+          record_from(y, v, u, rec);
+          store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
+        }
+      }
+      load_hist_vec<T, HS_LEAN>(L.hist + (size_t)(j + 1) * HS_LEAN, hv);
+      y = state_axpy(y, Pc.ds, k1);
+    };
+    if (storing || flush) {
+      for (int t = 0; t < R.sbase; ++t) point(std::true_type{}, R.s_i + t);
+      if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase);
+    } else {
+#pragma unroll KR_MS_UNROLL
+      for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t);
+      if (R.len_i > R.sbase) point(std::false_type{}, R.s_i + R.sbase);
+    }
+    if (st && iv == P - 1) {
+      T rec[KR_SLOTS];
+      record_from(y, S.vlast, S.ulast, rec);
+      store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+      if (S.tip) { S.tip[0] = y.p.x; S.tip[1] = y.p.y; S.tip[2] = y.p.z; }
+    }
+    if (flush) break;
+    ++it;
+
+    // ---- end states and forward-difference columns of this wavefront's intervals -------------------------
+    {
+      T er[19];
+      state_to_rows(y, er);
+      if (col == 0 && !idle) {
+#pragma unroll
+        for (int q = 0; q < 19; ++q) Es[lane * 19 + q] = er[q];
+      }
+      wave_sync();
+      if (col > 0) {
+        const T ih = fast_rcp(hstep);
+        T e0[19];
+#pragma unroll
+        for (int q = 0; q < 19; ++q) e0[q] = Es[R.l0own * 19 + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 19; ++q) Es[lane * 19 + q] = (er[q] - e0[q]) * ih;
+      }
+      wave_sync();
+    }
+    // c_k = E_k - Y_{g0+k+1} (0 for the very last interval), row r
+    auto cterm = [&](int k) -> T {
+      const int g = R.g0 + k;
+      const T e0 = Es[msw_l0(wave, k) * 19 + r];
+      return g < P - 1 ? e0 - Xs[(g + 1) * 19 + r] : T(0);
+    };
+    // ---- local condensation ----------------------------------------------------------------------------
+    T Xreg[3][2];   // wavefront 0: column pair of X_1 .. X_3
+    T Lreg[2][5];   // wavefront >= 1: columns kp, kp+4, kp+8, kp+12 (and 16 for kp == 0) of L_0, L_1
+    if (wave == 0) {
+      T* XB = Lt;  // [2][19][8] fits in the L tiles
+      {
+        const T c0 = cterm(0);
+        const T da = Es[(2 * kp) * 19 + r];
+        const T db = Es[(2 * kp + 1) * 19 + r];
+        Xreg[0][0] = kp == 0 ? c0 : da;
+        Xreg[0][1] = kp == 3 ? T(0) : db;
+        store_pair(XB + r * 8 + 2 * kp, Xreg[0][0], Xreg[0][1]);
+      }
+      wave_sync();
+#pragma unroll
+      for (int g = 1; g < 4; ++g) {
+        const T* xcur = XB + ((g - 1) & 1) * (19 * 8);
+        T* xnext = XB + (g & 1) * (19 * 8);
+        const int l0 = 7 + 17 * (g - 1);
+        T n0 = kp == 0 ? cterm(g) : T(0), n1 = T(0), n2 = T(0), n3 = T(0);
+        {
+          T av[16], xa[16], xb[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            av[c] = Es[(l0 + 1 + c) * 19 + r];
+            load_pair(xcur + (3 + c) * 8 + 2 * kp, xa[c], xb[c]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 16; c += 2) {
+            n0 = fma(av[c], xa[c], n0);
+            n1 = fma(av[c], xb[c], n1);
+            n2 = fma(av[c + 1], xa[c + 1], n2);
+            n3 = fma(av[c + 1], xb[c + 1], n3);
+          }
+          n0 += n2;
+          n1 += n3;
+        }
+        if (g < 3) {
+          Xreg[g][0] = n0;
+          Xreg[g][1] = n1;
+          store_pair(xnext + r * 8 + 2 * kp, n0, n1);
+        } else {
+          store_pair(L.Xbd + (size_t)1 * 19 * 8 + r * 8 + 2 * kp, n0, n1);  // X^(1): dY at wavefront 1's first interval
+        }
+        wave_sync();
+      }
+    } else {
+      // L_0 = [c | A] of the first interval; L_{k+1} = [c | 0] + A_{k+1} L_k
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const int cc = kp + 4 * m;  // column of L: 0 = a, 1..16 = B
+        T v = T(0);
+        if (cc == 0) v = cterm(0);
+        else if (cc <= 16 && (m < 4 || kp == 0)) v = Es[(msw_l0(wave, 0) + cc) * 19 + r];
+        Lreg[0][m] = v;
+        if (m < 4 || kp == 0) Lt[r * MSW_LT_LD + cc] = v;
+      }
+      wave_sync();
+#pragma unroll
+      for (int k = 1; k < 3; ++k) {
+        const T* lcur = Lt + ((k - 1) & 1) * (19 * MSW_LT_LD);
+        T* lnext = Lt + (k & 1) * (19 * MSW_LT_LD);
+        const int l0 = msw_l0(wave, k);
+        T acc[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc[m] = T(0);
+        if (kp == 0) acc[0] = cterm(k);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const T a = Es[(l0 + 1 + c) * 19 + r];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[m] = fma(a, lcur[(3 + c) * MSW_LT_LD + kp + 4 * m], acc[m]);
+          if (kp == 0) acc[4] = fma(a, lcur[(3 + c) * MSW_LT_LD + 16], acc[4]);
+        }
+        if (k < 2) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) Lreg[1][m] = acc[m];
+        }
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+          if (m < 4 || kp == 0) lnext[r * MSW_LT_LD + kp + 4 * m] = acc[m];
+        wave_sync();
+      }
+    }
+    __syncthreads();
+    // ---- boundary blocks down the rod: X^(w+1) = [a^w | 0] + B^w X^(w);  the last wavefront forms T dG = rhs ------
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+      if (wave == w) {
+        const T* l2 = Lt;  // after two stages the final map sits in tile 0
+        const T* xin = L.Xbd + (size_t)w * 19 * 8;
+        T n0 = kp == 0 ? l2[r * MSW_LT_LD + 0] : T(0), n1 = T(0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const T b = l2[r * MSW_LT_LD + 1 + c];
+          T xa, xb;
+          load_pair(xin + (3 + c) * 8 + 2 * kp, xa, xb);
+          n0 = fma(b, xa, n0);
+          n1 = fma(b, xb, n1);
+        }
+        if (w < W - 1) {
+          store_pair(L.Xbd + (size_t)(w + 1) * 19 * 8 + r * 8 + 2 * kp, n0, n1);
+        } else if (r >= 7 && r < 13) {
+          // tip rows: [n; m](E_last + dE_last) = [F_tip; M_tip]
+          const T e0 = Es[msw_l0(wave, 2) * 19 + r];
+          if (kp == 0) n0 = L.cold[CD_FTIP + (r - 7)] - e0 - n0;
+          store_pair(L.Tm + (r - 7) * 8 + 2 * kp, n0, n1);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- 6 x 6 solve, redundantly in every lane -----------------------------------------------------------
+    T d[6];
+    {
+      T a6[6][7];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        T row[8];
+        load_hist_vec<T, 8>(L.Tm + i * 8, row);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a6[i][k] = row[1 + k];
+        a6[i][6] = row[0];
+      }
+      solve6(a6, d);
+    }
+    // ---- updates of rows 3..18 of every unknown ---------------------------------------------------------------
+    const T dd0 = kp == 0 ? T(1) : kp == 1 ? d[1] : kp == 2 ? d[3] : d[5];
+    const T dd1 = kp == 0 ? d[0] : kp == 1 ? d[2] : kp == 2 ? d[4] : T(0);
+    auto quad_sum = [](T s) {
+      s += quad_xor<0xB1>(s);
+      s += quad_xor<0x4E>(s);
+      return s;
+    };
+    if (wave == 0) {
+#pragma unroll
+      for (int g = 1; g < 4; ++g) {
+        const T s = quad_sum(fma(Xreg[g - 1][1], dd1, Xreg[g - 1][0] * dd0));
+        if (kp == 0) L.dY[g * 19 + r] = s;
+      }
+      if (lane < 6) L.dY[0 * 19 + 7 + lane] = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : lane == 3 ? d[3] : lane == 4 ? d[4] : d[5];
+    } else {
+      T xa, xb;
+      load_pair(L.Xbd + (size_t)wave * 19 * 8 + r * 8 + 2 * kp, xa, xb);
+      const T s = quad_sum(fma(xb, dd1, xa * dd0));  // dY at this wavefront's first interval, row r
+      if (kp == 0) L.dY[R.g0 * 19 + r] = s;
+      wave_sync();
+      // inner intervals: dY_{g0+k+1} = L_k [1; dY_{g0}]
+      T yin[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int cc = kp + 4 * m;
+        yin[m] = cc == 0 ? T(1) : L.dY[R.g0 * 19 + 2 + cc];  // column cc multiplies dY_in[row 3 + cc - 1]
+      }
+      const T y16 = L.dY[R.g0 * 19 + 18];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        T part = T(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) part = fma(Lreg[k][m], yin[m], part);
+        if (kp == 0) part = fma(Lreg[k][4], y16, part);
+        part = quad_sum(part);
+        if (kp == 0) L.dY[(R.g0 + k + 1) * 19 + r] = part;
+      }
+    }
+    __syncthreads();
+    // ---- p rows: dY_{g+1}[p] = sum_{i<=g} (c_i[p] + A_i[p, :] dY_i[3:]) ------------------------------------------
+    if (lane < 3 * R.K) {
+      const int k = lane / 3, prow = lane - 3 * k;
+      const int g = R.g0 + k;
+      const int l0 = msw_l0(wave, k);
+      T s = g < P - 1 ? Es[l0 * 19 + prow] - Xs[(g + 1) * 19 + prow] : T(0);
+      T s2 = T(0);
+      if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s = fma(Es[(l0 + 1 + c) * 19 + prow], L.dY[0 * 19 + 7 + c], s);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+          s = fma(Es[(l0 + 1 + c) * 19 + prow], L.dY[g * 19 + 3 + c], s);
+          s2 = fma(Es[(l0 + 2 + c) * 19 + prow], L.dY[g * 19 + 4 + c], s2);
+        }
+      }
+      L.sp[g * 4 + prow] = s + s2;
+    }
+    __syncthreads();
+    // ---- scaled update norm over this wavefront's unknowns, then over the rod -----------------------------------
+    float dnf = 0.f;
+    T updP = T(0), xsP = T(0);
+    const bool plane = lane < 3 * R.K && R.g0 + lane / 3 + 1 < P;  // owns Y_{g0+k+1}[prow]
+    int pg = 0, pprow = 0;
+    if (plane) {
+      pg = R.g0 + lane / 3 + 1;
+      pprow = lane % 3;
+      xsP = Xs[pg * 19 + pprow];
+      for (int i = 0; i < pg; ++i) updP += L.sp[i * 4 + pprow];
+      dnf = update_ratio(updP, xsP);
+    }
+    // rows 3..18: lanes 0..15 (+16 k) own (row 3 + (lane & 15)) of the local unknown k
+    T updR[4], xsR[4];
+    int ng = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      updR[k] = T(0); xsR[k] = T(0);
+      const int g = wave == 0 ? 1 + k : R.g0 + k;       // unknown states owned by this wavefront
+      const bool own = (wave == 0 ? k < 3 : k < 3) && g < P && (lane >> 4) == k;
+      if (own) {
+        const int rr = 3 + (lane & 15);
+        xsR[k] = Xs[g * 19 + rr];
+        updR[k] = L.dY[g * 19 + rr];
+        dnf = fmaxf(dnf, update_ratio(updR[k], xsR[k]));
+      }
+    }
+    T updG = T(0), xsG = T(0);
+    const bool glane = wave == 0 && lane >= WAVE - 6;
+    if (glane) {
+      const int k = lane - (WAVE - 6);
+      xsG = Xs[0 * 19 + 7 + k];
+      updG = L.dY[0 * 19 + 7 + k];
+      dnf = fmaxf(dnf, update_ratio(updG, xsG));
+    }
+    (void)ng;
+    dnf = msw_max<W>(dnf, redf, wave, lane);
+    const bool finite = dnf <= 3.0e38f;
+    const T dn = (T)dnf;
+    if (finite && !below && dn <= S.tol) {
+      below = true;
+      if (dn_prev > T(0)) {
+        const T floor_dn = T(64) * (sizeof(T) == 8 ? T(2.2e-16) : T(1.2e-7));
+        const T k = fmax(dn, floor_dn) * fast_rcp(dn_prev * dn_prev);
+        S.kappa = fmin(fmax(k, T(1e-4)), T(1));
+      }
+    }
+    bool done = false;
+    if (!finite) {
+      done = true;
+      status = KR_ST_NONFINITE;
+      flush = !storing;
+    } else if (storing && dn <= S.tol) {
+      done = true;
+      status = KR_ST_CONVERGED;
+    } else {
+      if (plane) Xs[pg * 19 + pprow] = xsP + updP;
+      if (glane) Xs[0 * 19 + 7 + (lane - (WAVE - 6))] = xsG + updG;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int g = wave == 0 ? 1 + k : R.g0 + k;
+        if (k < 3 && g < P && (lane >> 4) == k) Xs[g * 19 + 3 + (lane & 15)] = xsR[k] + updR[k];
+      }
+      if (predict_final<T>(dn, dn_prev, S.tol, S.tolA)) storing = true;
+      if (kappa_in > T(0) && T(4) * kappa_in * dn * dn <= S.tol) storing = true;
+      dn_prev = dn;
+      if (it >= S.maxit) {
+        done = true;
+        status = KR_ST_MAXIT;
+        flush = true;
+      }
+    }
+    __syncthreads();
+    if (done && !flush) break;
+    if (done && flush) storing = false;
+  }
+  return status;
+}
+
+// ---- one time step per launch: one workgroup of W wavefronts per rod -----------------------------------------
+template <typename T, bool DIAG, int W>
+__global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc, const StepArgs<T> A) {
+  constexpr int P = MswGeo<W>::P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = Pc.N;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int64_t rod = blockIdx.x;
+  const size_t rod_elems = (size_t)N * KR_SLOTS;
+  const MswLds<T, W> L = msw_carve<T, W>(reinterpret_cast<T*>(smem_raw), N);
+  const MswRole R = msw_role<W>(wave, lane, N);
+  if (wave == 0) ms_cold_fill<T>(Pc, L.cold, lane);
+  // BDF2 history (knode.py:74-75), raw terms only
+  for (int j = threadIdx.x; j < N; j += WAVE * W) {
+    const size_t off = rod * rod_elems + (size_t)j * KR_SLOTS;
+    T cv[12], pv[12], hv[12];
+    load_hist_vec<T, 12>(A.cur + off, cv);
+    load_hist_vec<T, 12>(A.prev + off, pv);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[k] + A.hc2 * pv[k];
+    store_vec<T, 12>(L.hist + (size_t)j * HS_LEAN, hv);
+  }
+  __syncthreads();
+  V3<T> fconst;
+  {
+    V3<T> tf{T(0), T(0), T(0)};
+    const T* tens4 = A.tens + rod * A.tens_stride;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // cosserat_ode.py:195
+      const T tt = tens4[t];
+      tf.x += tt * L.cold[CD_TDIRS + t * 3 + 0];
+      tf.y += tt * L.cold[CD_TDIRS + t * 3 + 1];
+      tf.z += tt * L.cold[CD_TDIRS + t * 3 + 2];
+    }
+    fconst = {L.cold[CD_RHOAG] + tf.x, L.cold[CD_RHOAG + 1] + tf.y, L.cold[CD_RHOAG + 2] + tf.z};
+  }
+  MsSolveArgs<T> S;
+  {
+    const T* cl = A.cur + rod * rod_elems + (size_t)(N - 1) * KR_SLOTS;
+    S.vlast = {cl[SL_V], cl[SL_V + 1], cl[SL_V + 2]};
+    S.ulast = {cl[SL_U], cl[SL_U + 1], cl[SL_U + 2]};
+  }
+  S.out_rod = A.next + rod * rod_elems;
+  S.tip = A.tip ? A.tip + rod * A.tip_stride : nullptr;
+  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  S.kappa = T(0);
+  const int ne = R.K * 19;
+  T* Xl = L.Xs + R.g0 * 19;
+  int it, status;
+  if (A.pred) {
+    double* img = A.pred + ((size_t)rod * W + wave) * MS_PRED_ROWS * WAVE;
+    MsPred<T> Q;
+    if (A.pred_reset) mswp_init<T>(Q, lane, ne, R.g0, N, P, A.cur + rod * rod_elems, A.prev + rod * rod_elems, A.pred_has_prev != 0, A.pred_limit);
+    else ms_pred_load<T>(Q, img, lane);
+    S.kappa = Q.kappa;
+    int order = Q.next_order;
+    while (true) {
+      mswp_guess<T>(Q, order, lane, ne, wave == 0, L.cold, Xl);
+      wave_sync();
+      if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];  // caller's guess (knode.py:67,89)
+      __syncthreads();
+      status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it);
+      if (status == KR_ST_CONVERGED || order == 0) break;
+      order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
+      __syncthreads();
+    }
+    mswp_update<T, W>(Q, order, status, A.pred_limit, lane, wave, ne, Xl, L.red);
+    Q.kappa = S.kappa;
+    ms_pred_save<T>(Q, img, lane);
+  } else {
+    for (int e = lane; e < ne; e += WAVE) {
+      const int i = e / 19, rr = e - i * 19;
+      const int sj = msw_start(R.g0 + i, N, P);
+      const size_t off = rod * rod_elems + (size_t)sj * KR_SLOTS + ms_slot_of_yrow(rr);
+      T g = extrapolate<T>(A.pred_order, A.cur[off], A.prev[off], A.prev2 ? A.prev2[off] : T(0));
+      if (wave == 0 && i == 0) {
+        T bc;
+        if (ms_base_bc(L.cold, rr, bc)) g = bc;
+        else if (A.pred_order <= 0) g = A.G[rod * 6 + (rr - 7)];
+      }
+      Xl[e] = g;
+    }
+    __syncthreads();
+    status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it);
+  }
+  if (wave == 0 && lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * 19 + 7 + lane];
+  if (wave == 0 && lane == 0) {
+    if (A.status) A.status[rod * A.st_stride] = status;
+    if (A.iters) A.iters[rod * A.st_stride] = it;
+  }
+}
+
+template <typename T, int W>
+static size_t msw_lds_bytes(int N) { return sizeof(T) * msw_lds_elems<T, W>(N); }
+
+// wavefronts per rod this call should use (0: not this kernel).  Auto: long rods (no persistent form) in batches
+// that leave SIMDs idle; the option "waves_per_rod" forces 1 / 2 / 4.
+template <typename T>
+int step_waves_per_rod(kr_handle* h, int scheme, int use_nn, int64_t B, int mode) {
+  const RodConst<T>& P = consts<T>(h);
+  if (use_nn || scheme != KR_EULER || mode != 0 || h->ms_mode == 0) return 0;
+  auto fits = [&](int W, size_t bytes) {
+    if (P.N - 1 < 2 * (4 + 3 * (W - 1))) return false;
+    if (bytes > (size_t)h->lds_limit) return false;
+    const int64_t per_cu = (int64_t)((size_t)h->lds_limit / bytes);
+    return B <= 256 * per_cu && B * W <= 2048;
+  };
+  const size_t b2 = msw_lds_bytes<T, 2>(P.N), b4 = msw_lds_bytes<T, 4>(P.N);
+  if (h->waves_per_rod == 1) return 0;
+  if (h->waves_per_rod == 2) return fits(2, b2) ? 2 : 0;
+  if (h->waves_per_rod == 4) return fits(4, b4) ? 4 : 0;
+  if (P.N <= MS_NPL * WAVE) return 0;  // the persistent one-wavefront kernel serves these
+  if (B * 4 <= 1024 && fits(4, b4)) return 4;
+  if (B * 2 <= 1024 && fits(2, b2)) return 2;
+  return 0;
+}
+template <typename T, bool DIAG, int W>
+static int launch_msw_inst(const RodConst<T>& P, const StepArgs<T>& a, hipStream_t s) {
+  auto kern = msw_step_kernel<T, DIAG, W>;
+  const size_t smem = msw_lds_bytes<T, W>(P.N);
+  static thread_local size_t configured = 0;
+  if (smem > 48 * 1024 && smem > configured) {
+    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * W), smem, s, P, a);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+template <typename T>
+static int launch_msw(kr_handle* h, int W, const StepArgs<T>& a, hipStream_t s) {
+  const RodConst<T>& P = consts<T>(h);
+  h->last_sim_path = 1;
+  h->last_waves_per_rod = W;
+  if (W == 2) return P.diag ? launch_msw_inst<T, true, 2>(P, a, s) : launch_msw_inst<T, false, 2>(P, a, s);
+  return P.diag ? launch_msw_inst<T, true, 4>(P, a, s) : launch_msw_inst<T, false, 4>(P, a, s);
+}
+
+}  // namespace kr

@@ -689,7 +689,12 @@ template <typename T>
 static int launch_ms(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s);
 
 template <typename T>
+static int launch_msw(kr_handle* h, int W, const StepArgs<T>& a, hipStream_t s);
+
+template <typename T>
 int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s) {
+  h->last_waves_per_rod = 1;
+  if (const int W = step_waves_per_rod<T>(h, scheme, use_nn, a.B, a.mode)) return launch_msw<T>(h, W, a, s);
   if (ms_eligible<T>(h, use_nn, a)) return launch_ms<T>(h, scheme, use_nn, a, s);
   if (scheme == KR_EULER) return launch_step_nn<T, KR_EULER>(h, use_nn, a, s);
   if (scheme == KR_RK4) return launch_step_nn<T, KR_RK4>(h, use_nn, a, s);

@@ -15,10 +15,12 @@ MS_P = 4            # sub-intervals of the multiple-shooting kernels (kr_ms_impl
 PERSIST_MAX_N = 128  # the persistent kernel keeps the older history lane-per-grid-point in registers
 
 
-def set_mode_env(monkeypatch, mode):
-    """kr_create reads KR_MS_MODE / KR_PERSISTENT."""
+def set_mode_env(monkeypatch, mode, waves_per_rod=1):
+    """kr_create reads KR_MS_MODE / KR_PERSISTENT / KR_WAVES_PER_ROD.  The modes pin one wavefront per rod; the
+    several-wavefront form of path 1 (kr_msw_impl.hpp) has its own tests (test_gpu_msw.py)."""
     monkeypatch.setenv("KR_MS_MODE", "0" if mode == "single" else "1")
     monkeypatch.setenv("KR_PERSISTENT", "1" if mode == "persistent" else "0")
+    monkeypatch.setenv("KR_WAVES_PER_ROD", str(waves_per_rod))
 
 
 def make_robot(mod, N, use_fsolve=True):
@@ -84,7 +86,10 @@ def require_path(mode, N, mlp=None, scheme="euler"):
     return want
 
 
-def assert_path(robot_or_handle, want):
+def assert_path(robot_or_handle, want, waves_per_rod=1):
     h = robot_or_handle if hasattr(robot_or_handle, "get_option") else robot_or_handle._handle
     got = h.get_option("last_sim_path")
     assert got == want, f"kernel path {got} ran, the test is meant to exercise path {want}"
+    if want == 1:
+        w = h.get_option("last_waves_per_rod")
+        assert w == waves_per_rod, f"{w} wavefronts per rod ran, the test is meant to exercise {waves_per_rod}"

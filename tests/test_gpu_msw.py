@@ -1,0 +1,173 @@
+"""GPU parity tests (``-m gpu``) of the several-wavefronts-per-rod form of the multiple-shooting step kernel
+(kr_msw_impl.hpp; path 1 with ``last_waves_per_rod`` 2 or 4): the kernel long rods in small batches run
+(BASELINE cfg5, N = 400 at B <= 512).  Same bar as the one-wavefront kernel: the reference's fixtures
+(knode.py:46-101 run by tests/golden/make_golden.py), the CPU oracle, batch independence, a root of the shooting
+residual, fp32 inside the 1e-5 contract.  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+from gpu_helpers import assert_path, make_robot, set_mode_env
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(params=[2, 4])
+def waves(request, monkeypatch):
+    set_mode_env(monkeypatch, "multi", waves_per_rod=request.param)
+    return request.param
+
+
+def _n400_case(P):
+    if P == "1_0":
+        g = load_golden("sim_n400")
+        return g["ctl"], g["tip"], g["last"], g["ier"]
+    g = load_golden("sim_more")
+    return g[f"n400_P{P}_ctl"], g[f"n400_P{P}_tip"], g[f"n400_P{P}_last"], g[f"n400_P{P}_ier"]
+
+
+@pytest.mark.parametrize("P", ["0_5", "1_0", "2_0", "3_0"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_n400_vs_reference(torch_cuda, waves, P, dtype):
+    """calc_controls('sine', P), N = 400: tip path and last state against the reference's own run."""
+    from knode import simulate_batch
+    ctl, tip, last, ier = _n400_case(P)
+    assert np.all(ier == 1)
+    r = make_robot(None, 400)
+    T = len(tip) - 1
+    out = simulate_batch(r, ctl[None, :T], dtype=dtype)
+    assert_path(r, 1, waves)
+    assert np.all(out["status"] == 0)
+    got = np.concatenate([out["traj"][0, :1, :3, -1], out["tip"][0]])
+    assert rel_l2(got, tip) < (1e-8 if dtype == "f64" else 1e-5)
+    assert rel_l2(out["traj"][0, T], last) < (1e-7 if dtype == "f64" else 2e-5)
+
+
+@pytest.mark.parametrize("N", [27, 100, 131])
+@pytest.mark.parametrize("mod", [None, "dampstiff"])
+def test_other_grids_vs_oracle(torch_cuda, waves, N, mod):
+    """Grid sizes where the sub-intervals are ragged (N - 1 not a multiple of P = 7 / 13), a model-mismatch variant
+    of the rod (knode.py:6-53 'dampstiff'; full material matrices: test_full_matrices): 10 steps
+    against the C oracle."""
+    import cosserat_oracle as orc
+    import cosserat_oracle_c as oc
+    from knode import simulate_batch
+    if N - 1 < 2 * (4 + 3 * (waves - 1)):
+        pytest.skip("too few grid points for this many sub-intervals")
+    r = make_robot(mod, N)
+    T = 10
+    ctl = np.array(orc.calc_controls("sine", 2.0, r.del_t, T))
+    out = simulate_batch(r, ctl[None], dtype="f64")
+    assert_path(r, 1, waves)
+    assert np.all(out["status"] == 0)
+    tip_c, _, bad = oc.simulate(orc.params_for(mod, N), ctl)
+    assert bad == 0
+    assert rel_l2(out["tip"][0], tip_c) < 1e-8
+
+
+def test_full_matrices(torch_cuda, waves):
+    """Off-diagonal material matrices (the DIAG = false instantiation): a rod whose Bse / Bbt are full."""
+    import cosserat_oracle as orc
+    from knode import simulate_batch
+    r = make_robot(None, 60)
+    rng = np.random.default_rng(5)
+    S = rng.standard_normal((3, 3)) * 0.05
+    r.Bbt = r.Bbt @ (np.eye(3) + S + S.T)
+    r.Bse = r.Bse + 1e-3 * (S + S.T)
+    r.compute_intermediate_terms()
+    T = 8
+    ctl = np.array(orc.calc_controls("sine", 1.0, r.del_t, T))
+    out = simulate_batch(r, ctl[None], dtype="f64")
+    assert_path(r, 1, waves)
+    assert np.all(out["status"] == 0)
+    P = orc.params_for(None, 60)
+    P.Bbt = np.array(r.Bbt)
+    P.Bse = np.array(r.Bse)
+    ref = orc.simulate(P.derived(), np.vstack([ctl, ctl[-1:]]), solver="newton")[1:, :3, -1]
+    assert rel_l2(out["tip"][0], ref) < 1e-8
+
+
+def test_batch_properties(torch_cuda, waves):
+    """The cfg5 batch shape (N = 400; B = 512 for two wavefronts per rod, 256 for four), fp64 and fp32: every step
+    converges, the stored state is a root of the shooting residual, a rod's result does not depend on the batch
+    around it, fp32 within 1e-5 of fp64 at the tip, two rods against the C oracle, and the same trajectory as the
+    one-wavefront kernel to rounding."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    import cosserat_oracle_c as oc
+    r = make_robot(None, 400)
+    h = r._native()
+    B, T = (512 if waves == 2 else 256), 5
+    Ps = np.array([0.5, 1.0, 2.0, 3.0])
+    ctl = np.stack([np.array(orc.calc_controls("sine", float(Ps[b % 4]), r.del_t, T)) * (1.0 + 0.02 * (b // 4) / (B // 4))
+                    for b in range(B)])
+    tips = {}
+    for dt in (torch.float64, torch.float32):
+        ctl_t = torch.as_tensor(ctl, device=DEV).to(dt).contiguous()
+        states = h.new_state(B, dt, n_slots=T + 1)
+        h.init_straight(states[0])
+        G = torch.zeros((B, 6), dtype=dt, device=DEV)
+        status = torch.full((B, T), -1, dtype=torch.int32, device=DEV)
+        tip = torch.empty((B, T, 3), dtype=dt, device=DEV)
+        h.simulate(ctl_t, states, G, tip=tip, status=status)
+        torch.cuda.synchronize()
+        assert_path(h, 1, waves)
+        assert int((status != 0).sum()) == 0
+        tips[dt] = tip.double().cpu().numpy()
+        nxt = h.new_state(B, dt)
+        res = h.residual(G, states[T - 2], states[T - 1], nxt, ctl_t[:, T - 1].contiguous())
+        tol_r = 1e-8 if dt == torch.float64 else 2e-3
+        assert float(res.abs().max()) < tol_r * max(1.0, float(G.abs().max()))
+        st2 = h.new_state(3, dt, n_slots=T + 1)
+        h.init_straight(st2[0])
+        G2 = torch.zeros((3, 6), dtype=dt, device=DEV)
+        h.simulate(ctl_t[:3].contiguous(), st2, G2)
+        assert torch.equal(st2[T], states[T][:3])
+        assert float(states[T][..., 25:].abs().max()) == 0.0
+        # one wavefront per rod on the same inputs
+        h.set_option("waves_per_rod", 1)
+        st1 = h.new_state(8, dt, n_slots=T + 1)
+        h.init_straight(st1[0])
+        G1 = torch.zeros((8, 6), dtype=dt, device=DEV)
+        h.simulate(ctl_t[:8].contiguous(), st1, G1)
+        assert_path(h, 1, 1)
+        h.set_option("waves_per_rod", waves)
+        scale = float(st1[T].abs().max())
+        assert float((st1[T] - states[T][:8]).abs().max()) < (1e-9 if dt == torch.float64 else 2e-4) * scale
+    for b in range(B):
+        e = rel_l2(tips[torch.float32][b], tips[torch.float64][b])
+        assert e < 1e-5, (b, e)
+    for b in (1, B - 2):
+        tip_c, _, bad = oc.simulate(orc.params_for(None, 400), ctl[b])
+        assert bad == 0 and rel_l2(tips[torch.float64][b], tip_c) < 1e-8
+
+
+def test_auto_choice(torch_cuda, monkeypatch):
+    """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512, one beyond;
+    N = 100 (served by the persistent kernel) never takes this path."""
+    torch = torch_cuda
+    set_mode_env(monkeypatch, "persistent", waves_per_rod=0)
+    r = make_robot(None, 400)
+    h = r._native()
+    for B, want in ((1, 4), (256, 4), (257, 2), (512, 2), (513, 1)):
+        st = h.new_state(B, torch.float64, n_slots=3)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=torch.float64, device=DEV)
+        ctl = torch.zeros((B, 2, 4), dtype=torch.float64, device=DEV)
+        ctl[:, :, 0] = 1.0
+        h.simulate(ctl, st, G)
+        assert_path(h, 1, want)
+    r2 = make_robot(None, 100)
+    h2 = r2._native()
+    st = h2.new_state(4, torch.float64, n_slots=3)
+    h2.init_straight(st[0])
+    h2.simulate(torch.zeros((4, 2, 4), dtype=torch.float64, device=DEV), st, torch.zeros((4, 6), dtype=torch.float64, device=DEV))
+    assert_path(h2, 2)
