@@ -66,6 +66,7 @@ __device__ __forceinline__ MswRole msw_role(int wave, int lane, int N) {
   R.comp = R.col == 0 ? -1 : (R.iv == 0 ? 6 + R.col : 2 + R.col);
   return R;
 }
+__device__ __forceinline__ constexpr int msw_lpos(int cc) { return cc < 16 ? (cc & 3) * 4 + (cc >> 2) : 16; }  // column -> slot of an L tile row
 __device__ __forceinline__ int msw_l0(int wave, int k) { return wave == 0 ? (k == 0 ? 0 : 7 + 17 * (k - 1)) : 17 * k; }
 __device__ __forceinline__ int msw_start(int g, int N, int P) {
   const int nseg = N - 1, sbase = nseg / P, srem = nseg % P;
@@ -302,10 +303,14 @@ __device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status,
 // ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
 template <typename T, bool DIAG, int W>
 __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
-                                          V3<T> fconst, MsSolveArgs<T>& S, int& it) {
+                                          V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps) {
   constexpr int P = MswGeo<W>::P;
   const int N = Pc.N;
   const int wave = R.w;
+#ifdef KR_MS_STAMPS
+  unsigned long long tq;
+  KR_STAMP(tq);
+#endif
   T* Xs = L.Xs;
   T* Es = L.Es + (size_t)wave * ((64 * 19 + 3) & ~3);
   T* Lt = L.Lt + (size_t)wave * 2 * 19 * MSW_LT_LD;
@@ -367,6 +372,10 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
     }
     if (flush) break;
     ++it;
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.sweep, tq);
+    unsigned long long ta = tq;
+#endif
 
     // ---- end states and forward-difference columns of this wavefront's intervals -------------------------
     {
@@ -442,15 +451,19 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
         wave_sync();
       }
     } else {
-      // L_0 = [c | A] of the first interval; L_{k+1} = [c | 0] + A_{k+1} L_k
+      // L_0 = [c | A] of the first interval; L_{k+1} = [c | 0] + A_{k+1} L_k.  Column cc of a tile row sits at
+      // msw_lpos(cc): the four columns kp, kp + 4, kp + 8, kp + 12 of a lane are one 4-vector
+      {
+        T v4[4];
 #pragma unroll
-      for (int m = 0; m < 5; ++m) {
-        const int cc = kp + 4 * m;  // column of L: 0 = a, 1..16 = B
-        T v = T(0);
-        if (cc == 0) v = cterm(0);
-        else if (cc <= 16 && (m < 4 || kp == 0)) v = Es[(msw_l0(wave, 0) + cc) * 19 + r];
-        Lreg[0][m] = v;
-        if (m < 4 || kp == 0) Lt[r * MSW_LT_LD + cc] = v;
+        for (int m = 0; m < 4; ++m) {
+          const int cc = kp + 4 * m;  // column of L: 0 = a, 1..16 = B
+          v4[m] = cc == 0 ? cterm(0) : Es[(msw_l0(wave, 0) + cc) * 19 + r];
+          Lreg[0][m] = v4[m];
+        }
+        Lreg[0][4] = Es[(msw_l0(wave, 0) + 16) * 19 + r];
+        store_vec<T, 4>(Lt + r * MSW_LT_LD + 4 * kp, v4);
+        if (kp == 0) Lt[r * MSW_LT_LD + 16] = Lreg[0][4];
       }
       wave_sync();
 #pragma unroll
@@ -463,37 +476,67 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
         for (int m = 0; m < 5; ++m) acc[m] = T(0);
         if (kp == 0) acc[0] = cterm(k);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const T a = Es[(l0 + 1 + c) * 19 + r];
+        for (int half = 0; half < 2; ++half) {
+          // all LDS reads of eight columns back to back, then the arithmetic
+          T av[8], lv[8][4], l16[8];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc[m] = fma(a, lcur[(3 + c) * MSW_LT_LD + kp + 4 * m], acc[m]);
-          if (kp == 0) acc[4] = fma(a, lcur[(3 + c) * MSW_LT_LD + 16], acc[4]);
+          for (int c = 0; c < 8; ++c) {
+            const int cq = 8 * half + c;
+            av[c] = Es[(l0 + 1 + cq) * 19 + r];
+            load_hist_vec<T, 4>(lcur + (3 + cq) * MSW_LT_LD + 4 * kp, lv[c]);
+            l16[c] = lcur[(3 + cq) * MSW_LT_LD + 16];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = fma(av[c], lv[c][m], acc[m]);
+            acc[4] = fma(av[c], l16[c], acc[4]);
+          }
         }
         if (k < 2) {
 #pragma unroll
           for (int m = 0; m < 5; ++m) Lreg[1][m] = acc[m];
         }
-#pragma unroll
-        for (int m = 0; m < 5; ++m)
-          if (m < 4 || kp == 0) lnext[r * MSW_LT_LD + kp + 4 * m] = acc[m];
+        {
+          T v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+          store_vec<T, 4>(lnext + r * MSW_LT_LD + 4 * kp, v4);
+          if (kp == 0) lnext[r * MSW_LT_LD + 16] = acc[4];
+        }
         wave_sync();
       }
     }
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.a1, ta);
+#endif
     __syncthreads();
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.a2, ta);
+#endif
     // ---- boundary blocks down the rod: X^(w+1) = [a^w | 0] + B^w X^(w);  the last wavefront forms T dG = rhs ------
 #pragma unroll
     for (int w = 1; w < W; ++w) {
       if (wave == w) {
         const T* l2 = Lt;  // after two stages the final map sits in tile 0
         const T* xin = L.Xbd + (size_t)w * 19 * 8;
-        T n0 = kp == 0 ? l2[r * MSW_LT_LD + 0] : T(0), n1 = T(0);
+        T n0 = kp == 0 ? l2[r * MSW_LT_LD + 0] : T(0), n1 = T(0), n2 = T(0), n3 = T(0);
+        {
+          T bv[16], xa[16], xb[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const T b = l2[r * MSW_LT_LD + 1 + c];
-          T xa, xb;
-          load_pair(xin + (3 + c) * 8 + 2 * kp, xa, xb);
-          n0 = fma(b, xa, n0);
-          n1 = fma(b, xb, n1);
+          for (int c = 0; c < 16; ++c) {
+            bv[c] = l2[r * MSW_LT_LD + msw_lpos(1 + c)];
+            load_pair(xin + (3 + c) * 8 + 2 * kp, xa[c], xb[c]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 16; c += 2) {
+            n0 = fma(bv[c], xa[c], n0);
+            n1 = fma(bv[c], xb[c], n1);
+            n2 = fma(bv[c + 1], xa[c + 1], n2);
+            n3 = fma(bv[c + 1], xb[c + 1], n3);
+          }
+          n0 += n2;
+          n1 += n3;
         }
         if (w < W - 1) {
           store_pair(L.Xbd + (size_t)(w + 1) * 19 * 8 + r * 8 + 2 * kp, n0, n1);
@@ -506,6 +549,9 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       }
       __syncthreads();
     }
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.a3, ta);
+#endif
     // ---- 6 x 6 solve, redundantly in every lane -----------------------------------------------------------
     T d[6];
     {
@@ -567,15 +613,19 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       const int l0 = msw_l0(wave, k);
       T s = g < P - 1 ? Es[l0 * 19 + prow] - Xs[(g + 1) * 19 + prow] : T(0);
       T s2 = T(0);
-      if (g == 0) {
+      // uniform trip count (A_0 has 6 columns: the rest is masked) so that the reads can be issued together
+      T av[16], dv[16];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s = fma(Es[(l0 + 1 + c) * 19 + prow], L.dY[0 * 19 + 7 + c], s);
-      } else {
+      for (int c = 0; c < 16; ++c) {
+        const bool use = g > 0 || c < 6;
+        av[c] = use ? Es[(l0 + 1 + c) * 19 + prow] : T(0);
+        dv[c] = use ? L.dY[g * 19 + (g > 0 ? 3 : 7) + c] : T(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 16; c += 2) {
-          s = fma(Es[(l0 + 1 + c) * 19 + prow], L.dY[g * 19 + 3 + c], s);
-          s2 = fma(Es[(l0 + 2 + c) * 19 + prow], L.dY[g * 19 + 4 + c], s2);
-        }
+      for (int c = 0; c < 16; c += 2) {
+        s = fma(av[c], dv[c], s);
+        s2 = fma(av[c + 1], dv[c + 1], s2);
       }
       L.sp[g * 4 + prow] = s + s2;
     }
@@ -589,7 +639,11 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       pg = R.g0 + lane / 3 + 1;
       pprow = lane % 3;
       xsP = Xs[pg * 19 + pprow];
-      for (int i = 0; i < pg; ++i) updP += L.sp[i * 4 + pprow];
+#pragma unroll
+      for (int i = 0; i < P - 1; ++i) {
+        const T t = L.sp[i * 4 + pprow];
+        updP += i < pg ? t : T(0);
+      }
       dnf = update_ratio(updP, xsP);
     }
     // rows 3..18: lanes 0..15 (+16 k) own (row 3 + (lane & 15)) of the local unknown k
@@ -653,6 +707,11 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       }
     }
     __syncthreads();
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.a4, ta);
+    KR_STAMP_ADD(stamps.alg, tq);
+    if (it <= 4) stamps.dn[it - 1] = (double)dn;
+#endif
     if (done && !flush) break;
     if (done && flush) storing = false;
   }
@@ -671,6 +730,12 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
   const size_t rod_elems = (size_t)N * KR_SLOTS;
   const MswLds<T, W> L = msw_carve<T, W>(reinterpret_cast<T*>(smem_raw), N);
   const MswRole R = msw_role<W>(wave, lane, N);
+  MsStamps stamps;
+#ifdef KR_MS_STAMPS
+  unsigned long long t_begin, tp;
+  KR_STAMP(t_begin);
+  tp = t_begin;
+#endif
   if (wave == 0) ms_cold_fill<T>(Pc, L.cold, lane);
   // BDF2 history (knode.py:74-75), raw terms only
   for (int j = threadIdx.x; j < N; j += WAVE * W) {
@@ -709,6 +774,9 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
   const int ne = R.K * 19;
   T* Xl = L.Xs + R.g0 * 19;
   int it, status;
+#ifdef KR_MS_STAMPS
+  KR_STAMP_ADD(stamps.prep, tp);
+#endif
   if (A.pred) {
     double* img = A.pred + ((size_t)rod * W + wave) * MS_PRED_ROWS * WAVE;
     MsPred<T> Q;
@@ -721,14 +789,20 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       wave_sync();
       if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];  // caller's guess (knode.py:67,89)
       __syncthreads();
-      status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it);
+      status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
     }
+#ifdef KR_MS_STAMPS
+    KR_STAMP(tp);
+#endif
     mswp_update<T, W>(Q, order, status, A.pred_limit, lane, wave, ne, Xl, L.red);
     Q.kappa = S.kappa;
     ms_pred_save<T>(Q, img, lane);
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.osum, tp);
+#endif
   } else {
     for (int e = lane; e < ne; e += WAVE) {
       const int i = e / 19, rr = e - i * 19;
@@ -743,13 +817,33 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       Xl[e] = g;
     }
     __syncthreads();
-    status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it);
+    status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
   }
   if (wave == 0 && lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * 19 + 7 + lane];
   if (wave == 0 && lane == 0) {
     if (A.status) A.status[rod * A.st_stride] = status;
     if (A.iters) A.iters[rod * A.st_stride] = it;
   }
+#ifdef KR_MS_STAMPS
+  // diagnostic build (tools/msw_stamps.py): the debug buffer is [15][B][T] int32, plane k = quantity k of wavefront W-1
+  if (wave == W - 1 && lane == 0 && A.iters) {
+    unsigned long long t_end;
+    KR_STAMP(t_end);
+    const size_t plane = (size_t)A.B * A.st_stride;
+    int32_t* o = A.iters + rod * A.st_stride;
+    o[1 * plane] = (int32_t)(t_end - t_begin);
+    o[2 * plane] = (int32_t)stamps.prep;
+    o[3 * plane] = (int32_t)stamps.sweep;
+    o[4 * plane] = (int32_t)stamps.alg;
+    o[5 * plane] = (int32_t)stamps.osum;
+    o[6 * plane] = (int32_t)stamps.a1;
+    o[7 * plane] = (int32_t)stamps.a2;
+    o[8 * plane] = (int32_t)stamps.a3;
+    o[9 * plane] = (int32_t)stamps.a4;
+    for (int k = 0; k < 4; ++k) o[(10 + k) * plane] = __float_as_int((float)stamps.dn[k]);
+    o[14 * plane] = __float_as_int((float)S.kappa);
+  }
+#endif
 }
 
 template <typename T, int W>

@@ -29,7 +29,7 @@ def timed(h, B, T, dtype, warm=40):
 args = [int(a) for a in sys.argv[1:]] or [400, 512, 400, 256, 400, 64, 100, 256, 100, 64, 200, 256]
 for N, B in zip(args[0::2], args[1::2]):
     r = robot(N); h = r._native()
-    h.set_option("persistent", 0)
+    h.set_option("persistent", 0); h.set_option("keep_predictor", 1)
     for dt in (torch.float64, torch.float32):
         ref = None
         for W in (1, 2, 4):
