@@ -101,6 +101,153 @@ class _MlpFunction(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+def _point_map_graph(rod, handle, y, yh, zh, tf, cut=True):
+    """Autograd graph of the physics of one grid point, y[Q, 19] -> (y_s[Q, 19], z[Q, 6]), in fp64 - used only for the
+    backward pass of ``getResidualEuler`` (the values themselves come from the HIP kernels).
+
+    ``cut=True`` reproduces the graph the reference's ``ODE`` builds (cosserat_ode_torch.py:137-213), which is not the
+    graph of the function it evaluates: the quadratic part of the rotation matrix (:159-162) and the quaternion-rate
+    matrix (:185-189) are assembled with ``torch.tensor([...])``, i.e. as new leaves.  Through R, h is seen only via
+    the factor 2 / (h . h); h_s sees h but not u.  ``cut=False`` differentiates everything."""
+    f64 = torch.float64
+    dev = y.device
+    d = handle.derived()
+    mat = lambda a: torch.tensor(np.array(a, dtype=np.float64).reshape(3, 3), dtype=f64, device=dev)
+    vec = lambda a: torch.tensor(np.array(a, dtype=np.float64).reshape(-1), dtype=f64, device=dev)
+    tn = lambda a: torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64), device=dev)
+    Ksei, Kbti, rhoJ = mat(d.Kse_plus_c0_Bse_inv), mat(d.Kbt_plus_c0_Bbt_inv), mat(d.rhoJ)
+    Kse_vstar, rhoAg = vec(d.Kse_vstar), vec(d.rhoAg)
+    Bse, Bbt, Cd = tn(rod.Bse).reshape(3, 3), tn(rod.Bbt).reshape(3, 3), tn(rod.C).reshape(3)
+    c0, rhoA = float(d.c0), float(d.rhoA)
+    hq, n, m, q, w = y[:, 3:7], y[:, 7:10], y[:, 10:13], y[:, 13:16], y[:, 16:19]
+    vh, uh = zh[:, 0:3], zh[:, 3:6]
+    a, b, c, e = (hq.detach() if cut else hq).unbind(dim=1)
+    quad = torch.stack([torch.stack([-c * c - e * e, b * c - e * a, b * e + c * a], dim=1),
+                        torch.stack([b * c + e * a, -b * b - e * e, c * e - b * a], dim=1),
+                        torch.stack([b * e - c * a, c * e + b * a, -b * b - c * c], dim=1)], dim=1)
+    R = torch.eye(3, dtype=f64, device=dev) + (2.0 / (hq * hq).sum(dim=1))[:, None, None] * quad
+    rot = lambda x: torch.einsum("qij,qj->qi", R, x)
+    rot_t = lambda x: torch.einsum("qji,qj->qi", R, x)
+    cross = lambda p_, q_: torch.linalg.cross(p_, q_, dim=1)
+    v = (rot_t(n) + Kse_vstar - vh @ Bse.t()) @ Ksei.t()
+    u = (rot_t(m) - uh @ Bbt.t()) @ Kbti.t()
+    z = torch.cat([v, u], dim=1)
+    qt, wt = c0 * q + yh[:, 13:16], c0 * w + yh[:, 16:19]
+    vt, ut = c0 * v + vh, c0 * u + uh
+    load = rhoAg - rot(Cd * q * q.abs()) + tf
+    ps = rot(v)
+    ns = rhoA * rot(cross(w, q) + qt) - load
+    ms = rot(cross(w, w @ rhoJ.t()) + wt @ rhoJ.t()) - cross(ps, n)
+    qs = vt - cross(u, q) + cross(w, v)
+    ws = ut - cross(u, w)
+    u0, u1, u2 = (u.detach() if cut else u).unbind(dim=1)
+    o = torch.zeros_like(u0)
+    omega = torch.stack([torch.stack([o, -u0, -u1, -u2], dim=1), torch.stack([u0, o, u2, -u1], dim=1),
+                         torch.stack([u1, -u2, o, u0], dim=1), torch.stack([u2, u1, -u0, o], dim=1)], dim=1)
+    hs = 0.5 * torch.einsum("qij,qj->qi", omega, hq)
+    return torch.cat([ps, hs, ns, ms, qs, ws], dim=1), z
+
+
+class _SweepFunction(torch.autograd.Function):
+    """``CosseratRodTorch.getResidualEuler`` with autograd (cosserat_ode_torch.py:325-367 builds the graph op by op).
+
+    Forward: the shooting-residual kernel (``kr_residual_batch``).  Backward: the discrete adjoint of the Euler sweep,
+        lam_j = dL/dy_j = g_full[:19, j] + lam_{j+1} + J_j^T [ds lam_{j+1}; g_full[19:, j+1]],
+    where J_j (25 x 19) is the Jacobian of one grid point's map y_j -> (y_s, z) including the network correction:
+    the physics part from ``_point_map_graph`` (all N - 1 points at once), the network's input Jacobian from forward
+    differences of the device MLP (``kr_mlp_eval_batch``, fp64).  dL/dG = lam_0[7:13]; the parameter gradients are
+    ``kr_mlp_backward`` on the rows x_j = [y_j, z_j before the correction, tendon force] with output gradients
+    [ds lam_{j+1}; g_full[19:, j+1]].  Inputs other than G and the parameters (history, tensions) get no gradient.
+    By default the adjoint follows the reference's GRAPH, which differs from the function it computes in two places
+    (see ``_point_map_graph``); ``rod.exact_sweep_gradient = True`` gives the true gradient instead."""
+
+    @staticmethod
+    def forward(ctx, rod, G, *params):
+        total, full, r = rod._sweep_forward(G)
+        ctx.rod = rod
+        ctx.n_params = len(params)
+        ctx.save_for_backward(rod.y.detach().clone(), r.detach().clone(), *[p.detach() for p in params])
+        ctx.hist = (rod.residualArgs["yh"].detach().clone(), rod.residualArgs["zh"].detach().clone(),
+                    rod.tendon_tensions.detach().clone())
+        return total, full
+
+    @staticmethod
+    def backward(ctx, g_total, g_full):
+        rod = ctx.rod
+        y, r, *params = ctx.saved_tensors
+        yh, zh, tens = ctx.hist
+        h = rod._native()
+        dev = y.device
+        N = int(rod.N)
+        ds = float(h.derived().ds)
+        f64 = torch.float64
+        use_nn = bool(rod.use_nn)
+        if use_nn:
+            struct = mlp_structure(rod.nn_models)
+            h.set_mlp([p.cpu().numpy() for p in params[0::2]], [p.cpu().numpy() for p in params[1::2]],
+                      [a for _, a in struct])
+        if g_full is None:
+            g_full = torch.zeros((25, N), dtype=torch.float32, device=dev)
+        if g_total is None:
+            g_total = torch.zeros((), dtype=torch.float32, device=dev)
+        gf = g_full.to(f64)
+        # ---- Jacobians of the N - 1 grid-point maps y_j -> (y_s, z), [Q, 25, 19] ----
+        Q = N - 1
+        yq = y[:, :Q].t().to(f64).contiguous().requires_grad_(True)   # [Q, 19]
+        yhq = yh.float().to(dev)[:, :Q].t().to(f64).contiguous()
+        zhq = zh.float().to(dev)[:, :Q].t().to(f64).contiguous()
+        tdirs = torch.as_tensor(np.asarray(rod.tendon_dirs.detach().cpu() if torch.is_tensor(rod.tendon_dirs)
+                                           else rod.tendon_dirs), dtype=f64, device=dev).reshape(4, 3)
+        tf = (tens.to(dev).to(f64).reshape(1, 4) @ tdirs).expand(Q, 3).contiguous()
+        with torch.enable_grad():
+            ys_p, z_p = _point_map_graph(rod, h, yq, yhq, zhq, tf, cut=not getattr(rod, "exact_sweep_gradient", False))
+            Fp = torch.cat([ys_p, z_p], dim=1)
+            J = torch.stack([torch.autograd.grad(Fp[:, o].sum(), yq, retain_graph=True)[0] for o in range(25)], dim=1)
+        yq = yq.detach()
+        z_p = z_p.detach()
+        if use_nn:
+            # correction added after the physics (cosserat_ode_torch.py:192-213): out = MLP([y, z, f_tendon]).  Its
+            # input Jacobian from forward differences of the device MLP (fp64), chained with dz/dy of the physics
+            hist_in = params[0].shape[1] != 28
+            x0 = torch.cat([yq, yhq, z_p, zhq, tf], dim=1) if hist_in else torch.cat([yq, z_p, tf], dim=1)
+            n_in = x0.shape[1]
+            stepx = 1e-7 * torch.clamp(x0.abs(), min=1.0)
+            xp = x0.unsqueeze(1).repeat(1, n_in + 1, 1)
+            ii = torch.arange(n_in, device=dev)
+            xp[:, 1 + ii, ii] += stepx
+            o = h.mlp_eval(xp.reshape(Q * (n_in + 1), n_in).contiguous()).reshape(Q, n_in + 1, 25)
+            Jx = (o[:, 1:, :] - o[:, :1, :]) / stepx.unsqueeze(2)           # [Q, in, 25]
+            dxdy = torch.zeros((Q, n_in, 19), dtype=f64, device=dev)
+            dxdy[:, :19, :] = torch.eye(19, dtype=f64, device=dev)
+            z0 = 38 if hist_in else 19
+            dxdy[:, z0:z0 + 6, :] = J[:, 19:25, :]
+            J = J + torch.einsum("qio,qid->qod", Jx, dxdy)
+        # ---- adjoint recursion ----
+        lam = gf[:19, N - 1].clone()
+        lam[7:13] += -2.0 * g_total.to(f64) * r.to(f64)         # total = sum((F_tip - n_L)^2 + (M_tip - m_L)^2)
+        gout = torch.zeros((Q, 25), dtype=f64, device=dev)
+        for j in range(N - 2, -1, -1):
+            gout[j, :19] = ds * lam
+            gout[j, 19:] = gf[19:, j + 1]
+            lam = gf[:19, j] + lam + J[j].t() @ gout[j]
+        dG = lam[7:13].float()
+        grads = [None] * ctx.n_params
+        if use_nn and ctx.n_params:
+            # rows of the network: [y_j, z_j of the physics alone, tendon force]
+            in_dim = n_in
+            x = torch.zeros((Q, (in_dim + 31) // 32 * 32), dtype=torch.float32, device=dev)
+            x[:, :in_dim] = x0.float()
+            dims = tuple([in_dim] + [p.shape[0] for p in params[0::2]])
+            acts = tuple(a for _, a in struct)
+            leaves = [p.clone().requires_grad_(True) for p in params]
+            with torch.enable_grad():
+                out = _MlpFunction.apply(h, x, dims, acts, *leaves)
+            g32 = torch.zeros_like(out)
+            g32[:, :25] = gout.float()
+            grads = list(torch.autograd.grad(out, leaves, grad_outputs=g32))
+        return (None, dG, *grads)
+
+
 class CosseratRodTorch:
     def __init__(self, device, n_layers, nn_input_history=False):
         self.device = device
@@ -314,7 +461,17 @@ class CosseratRodTorch:
 
     def getResidualEuler(self, G):
         """cosserat_ode_torch.py:325-367: one full shooting sweep from the guessed base wrench
-        G[6] -> (sum of squared tip residuals, full_rod[25,N]).  Forward only."""
+        G[6] -> (sum of squared tip residuals, full_rod[25,N]).  Differentiable with respect to G and the MLP
+        parameters (what the reference's autograd graph reaches from a caller's point of view): forward on the
+        shooting kernel, backward as an adjoint sweep (``_SweepFunction``)."""
+        params = []
+        if self.use_nn:
+            for l, _ in mlp_structure(self.nn_models):
+                params += [l.weight, l.bias]
+        total, full = _SweepFunction.apply(self, G, *params)
+        return total, full
+
+    def _sweep_forward(self, G):
         h = self._native()
         N = int(self.N)
         dev = G.device
@@ -334,4 +491,4 @@ class CosseratRodTorch:
         full = torch.cat([torch.cat([y_new[0, :, :1], z_in[:, :1]], dim=0),
                           torch.cat([y_new[0, :, 1:], z_new[0, :, : N - 1]], dim=0)], dim=1)
         self.y = y_new[0]
-        return torch.sum(r[0] ** 2), full
+        return torch.sum(r[0] ** 2), full, r[0]

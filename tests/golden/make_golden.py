@@ -539,6 +539,41 @@ def gen_sim_more():
     save("sim_more", **out)
 
 
+def gen_tres_grad():
+    """a14 with autograd: gradients of  L = total_residual + sum(full_rod * Wgt)  (cosserat_ode_torch.py:325-367) with
+    respect to the guessed base wrench G and every MLP parameter, on the inputs of the `tres_*` entries of
+    sim_more.npz (same state, same network; use_nn 0 and 1)."""
+    g = np.load(os.path.join(HERE, "sim_more.npz"))
+    mlp = orc.Mlp([g[f"mlp_tres_W{k}"] for k in range(2)], [g[f"mlp_tres_b{k}"] for k in range(2)],
+                  [int(a) for a in g["mlp_tres_acts"]], bool(g["mlp_tres_history"]))
+    y, z, yp, zp, tens = g["tres_y"], g["tres_z"], g["tres_yp"], g["tres_zp"], g["tres_tens"]
+    G = g["tres_G"][1]
+    rng = np.random.default_rng(21)
+    Wgt = rng.standard_normal((25, y.shape[1])).astype(np.float32)
+    out = {"Wgt": Wgt}
+    for use_nn in (0, 1):
+        rob = ref_torch.CosseratRodTorch("cpu", 64)
+        ref_knode.setup_robot(rob, None)
+        rob.nn_models = torch_module_list(mlp)
+        rob.use_nn = bool(use_nn)
+        ty, tz = torch.tensor(y).float(), torch.tensor(z).float()
+        typ, tzp = torch.tensor(yp).float(), torch.tensor(zp).float()
+        rob.y, rob.z = ty.clone(), tz.clone()
+        rob.tendon_tensions = torch.tensor(tens).float()
+        rob.residualArgs["yh"] = rob.c1 * ty + rob.c2 * typ
+        rob.residualArgs["zh"] = rob.c1 * tz + rob.c2 * tzp
+        Gt = torch.tensor(G).float().requires_grad_(True)
+        tot, full = rob.getResidualEuler(Gt)
+        L = tot + (full * torch.tensor(Wgt)).sum()
+        L.backward()
+        out[f"L_{use_nn}"] = np.array(float(L))
+        out[f"dG_{use_nn}"] = Gt.grad.numpy().copy()
+        if use_nn:
+            for k, prm in enumerate(rob.nn_models.parameters()):
+                out[f"dparam{k}"] = prm.grad.numpy().copy()
+    save("tres_grad", **out)
+
+
 def gen_small():
     """F8: calc_controls and quaternion_to_euler."""
     out = {}
@@ -560,7 +595,7 @@ ALL = {
     "ode_kat": gen_ode_kat, "ode_torch_kat": gen_ode_torch_kat, "residual_kat": gen_residual_kat,
     "sim_cfg1": gen_sim_cfg1, "sim_n100": gen_sim_n100, "sim_n400": gen_sim_n400, "sim_misc": gen_sim_misc,
     "sim_nn": gen_sim_nn, "sim_more": gen_sim_more, "train_step": gen_train_step, "small": gen_small,
-    "checkpoint": gen_checkpoint, "estimate_state": gen_estimate_state,
+    "checkpoint": gen_checkpoint, "estimate_state": gen_estimate_state, "tres_grad": gen_tres_grad,
 }
 
 if __name__ == "__main__":

@@ -89,7 +89,7 @@ def test_simulate_lbfgs_branch(torch_cuda, shooting_mode):
 
 
 # ---------------------------------------------------------------------------
-# a14: differentiable full sweep of the torch twin (forward)
+# a14: differentiable full sweep of the torch twin
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("use_nn", [0, 1])
 def test_torch_full_sweep(torch_cuda, use_nn):
@@ -115,9 +115,74 @@ def test_torch_full_sweep(torch_cuda, use_nn):
         total, full = rob.getResidualEuler(t(G))
         ref_val = float(g[f"tres_val_{use_nn}"][k])
         assert full.shape == (25, 10)
-        assert abs(float(total) - ref_val) < 1e-4 * ref_val
-        assert rel_l2(full.cpu().numpy(), g[f"tres_full_{use_nn}"][k]) < 2e-6
+        assert abs(float(total.detach()) - ref_val) < 1e-4 * ref_val
+        assert full.requires_grad == bool(use_nn)  # like the reference's graph: reaches the MLP parameters
+        assert rel_l2(full.detach().cpu().numpy(), g[f"tres_full_{use_nn}"][k]) < 2e-6
         assert rel_l2(rob.y.cpu().numpy(), g[f"tres_yafter_{use_nn}"][k]) < 2e-6
+
+
+@pytest.mark.parametrize("use_nn", [0, 1])
+def test_torch_full_sweep_autograd(torch_cuda, use_nn):
+    """a14 with autograd: L = total_residual + sum(full_rod * Wgt); dL/dG and dL/d(every MLP parameter) against the
+    reference's autograd through cosserat_ode_torch.py:325-367 (tests/golden/make_golden.py gen_tres_grad; fp32 graph
+    there, adjoint sweep with fp64 forward-difference Jacobians here)."""
+    torch = torch_cuda
+    from cosserat_ode_torch import CosseratRodTorch
+    from knode import setup_robot
+    g, gg = load_golden("sim_more"), load_golden("tres_grad")
+    rob = CosseratRodTorch(DEV, 64)
+    setup_robot(rob, None)
+    with torch.no_grad():
+        rob.nn_models[0].weight.copy_(torch.tensor(g["mlp_tres_W0"]))
+        rob.nn_models[0].bias.copy_(torch.tensor(g["mlp_tres_b0"]))
+        rob.nn_models[2].weight.copy_(torch.tensor(g["mlp_tres_W1"]))
+        rob.nn_models[2].bias.copy_(torch.tensor(g["mlp_tres_b1"]))
+    rob.use_nn = bool(use_nn)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    y, z, yp, zp = t(g["tres_y"]), t(g["tres_z"]), t(g["tres_yp"]), t(g["tres_zp"])
+    rob.y, rob.z = y.clone(), z.clone()
+    rob.tendon_tensions = t(g["tres_tens"])
+    rob.residualArgs["yh"] = rob.c1 * y + rob.c2 * yp
+    rob.residualArgs["zh"] = rob.c1 * z + rob.c2 * zp
+    G = t(g["tres_G"][1]).requires_grad_(True)
+    total, full = rob.getResidualEuler(G)
+    L = total + (full * t(gg["Wgt"])).sum()
+    L.backward()
+    assert abs(float(L.detach()) - float(gg[f"L_{use_nn}"])) < 2e-5 * abs(float(gg[f"L_{use_nn}"]))
+    assert rel_l2(G.grad.cpu().numpy(), gg[f"dG_{use_nn}"]) < 1e-4
+    if use_nn:
+        for k, prm in enumerate(rob.nn_models.parameters()):
+            assert rel_l2(prm.grad.cpu().numpy(), gg[f"dparam{k}"]) < 1e-3, k
+    else:
+        assert all(prm.grad is None for prm in rob.nn_models.parameters())
+    # the graph the backward pass differentiates evaluates to what the HIP ODE kernel computes
+    from cosserat_ode_torch import _point_map_graph
+    h = rob._native()
+    f64 = torch.float64
+    yq = y.t().to(f64).contiguous()
+    yhq = (rob.c1 * y + rob.c2 * yp).t().to(f64).contiguous()
+    zhq = (rob.c1 * z + rob.c2 * zp).t().to(f64).contiguous()
+    tf = (t(g["tres_tens"]).to(f64).reshape(1, 4) @ rob.tendon_dirs.to(f64).reshape(4, 3)).expand(10, 3).contiguous()
+    ys_k, z_k = h.ode_batch(yq, yhq, zhq, tf, use_nn=False)
+    ys_g, z_g = _point_map_graph(rob, h, yq, yhq, zhq, tf)
+    assert rel_l2(ys_g.cpu().numpy(), ys_k.cpu().numpy()) < 1e-12
+    assert rel_l2(z_g.cpu().numpy(), z_k.cpu().numpy()) < 1e-12
+    # exact_sweep_gradient: the gradient of the function itself, against forward differences of the fp32 sweep (coarse)
+    rob.exact_sweep_gradient = True
+    G2 = t(g["tres_G"][1]).requires_grad_(True)
+    rob.y, rob.z = y.clone(), z.clone()
+    tot2, _ = rob.getResidualEuler(G2)
+    tot2.backward()
+    eps = 1e-3
+    fd = []
+    for k in range(6):
+        Gp = t(g["tres_G"][1]).double()
+        Gp[k] += eps
+        rob.y, rob.z = y.clone(), z.clone()
+        with torch.no_grad():
+            tp, _ = rob.getResidualEuler(Gp.float())
+        fd.append((float(tp) - float(tot2.detach())) / eps)
+    assert rel_l2(G2.grad.cpu().numpy(), np.array(fd)) < 2e-2
 
 
 # ---------------------------------------------------------------------------
