@@ -196,6 +196,27 @@ def test_torch_full_sweep(use_nn):
         assert abs(np.sum(r * r) - g[f"tres_val_{use_nn}"][k]) < 2e-4 * g[f"tres_val_{use_nn}"][k]
         assert rel_l2(full, g[f"tres_full_{use_nn}"][k]) < 1e-5
         assert rel_l2(y, g[f"tres_yafter_{use_nn}"][k]) < 1e-5
+        if k == 1:
+            # inputs of the gradient fixture (tres_grad.npz: reference autograd through the same sweep): its loss value
+            # from the oracle, and dL/dG against central differences of the oracle with the network off - where the
+            # reference's graph (cosserat_ode_torch.py:185-189 cuts u out of the quaternion rate) loses only the
+            # rotation's response to the base moment: same sign and size, not the same number
+            gg = load_golden("tres_grad")
+            L = np.sum(r * r) + np.sum(full * gg["Wgt"])
+            assert abs(L - gg[f"L_{use_nn}"]) < 2e-4 * abs(gg[f"L_{use_nn}"])
+            if not use_nn:
+                fd = np.zeros(6)
+                for c in range(6):
+                    vals = []
+                    for sgn in (1.0, -1.0):
+                        Gp = G.astype(np.float64).copy()
+                        Gp[c] += sgn * 1e-6
+                        yy, zz = y0.copy(), z0.copy()
+                        rr = orc.residual_euler(D, Gp, yy, zz, yh, zh, g["tres_tens"], None)
+                        ff = np.vstack([yy, np.hstack([z0[:, :1], zz[:, :-1]])])
+                        vals.append(np.sum(rr * rr) + np.sum(ff * gg["Wgt"]))
+                    fd[c] = (vals[0] - vals[1]) / 2e-6
+                assert rel_l2(gg["dG_0"], fd) < 0.1 and rel_l2(gg["dG_0"][:3], fd[:3]) < 0.02
 
 
 def test_controls_and_euler():
