@@ -16,9 +16,11 @@ What runs where:
                              training loop (torch loss -> ``backward()`` -> Adam) works unchanged
   * parameters, optimizer .. plain torch tensors (``nn.ModuleList`` of ``nn.Linear`` / ``nn.ELU``)
 
-Gradients are produced for the MLP parameters only.  The reference additionally
-lets autograd flow into the *inputs* of ``ODE_parallel`` (cosserat_ode_torch.py:264-306);
-no caller uses those gradients and they are not provided here.
+Gradients: the training paths produce them for the MLP parameters (what the reference's loops use).
+``getResidualEuler(G)`` is differentiable with respect to G and the parameters through an adjoint sweep
+(``_SweepFunction``), and ``ODE_parallel`` hands gradients to its *inputs* when they are asked for
+(cosserat_ode_torch.py:264-306 lets autograd flow there; no caller of the reference uses it) - both off the hot
+path: vector-Jacobian products of an fp64 torch graph of one grid point whose values are pinned to the ODE kernel.
 """
 from __future__ import annotations
 
@@ -29,6 +31,10 @@ import torch.nn as nn
 import krod_native as kn
 
 _ACT_CODE = {nn.Tanh: kn.ACT_TANH, nn.Softplus: kn.ACT_SOFTPLUS, nn.ReLU: kn.ACT_RELU, nn.ELU: kn.ACT_ELU}
+
+
+_ACT_FN = {kn.ACT_NONE: lambda t: t, kn.ACT_TANH: torch.tanh, kn.ACT_SOFTPLUS: nn.functional.softplus,
+           kn.ACT_RELU: torch.relu, kn.ACT_ELU: nn.functional.elu}
 
 
 def mlp_structure(modules):
@@ -74,6 +80,7 @@ class _MlpFunction(torch.autograd.Function):
         kn.check(handle.lib.kr_mlp_forward(handle._h, Q, n, dims_c, acts_c, Wp, bp, kn._ptr(x), x.shape[1],
                                            kn._ptr(out), kn._ptr(ws), kn._stream()))
         ctx.handle, ctx.dims, ctx.acts = handle, dims, acts
+        ctx.biases = [b.detach() for b in bs]
         ctx.save_for_backward(x, ws, *Ws)
         return out
 
@@ -98,7 +105,19 @@ class _MlpFunction(torch.autograd.Function):
         grads = []
         for a, b in zip(dW, db):
             grads += [a, b]
-        return (None, None, None, None, *grads)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            # Gradient with respect to the input rows - no caller of the reference asks for it (its training loops feed
+            # data), so there is no kernel for it: the layer stack once more as library GEMMs under autograd.
+            with torch.enable_grad():
+                xin = x[:, :dims[0]].detach().requires_grad_(True)
+                a_ = xin
+                for k in range(n):
+                    a_ = _ACT_FN[acts[k]](a_ @ Ws[k].t() + ctx.biases[k])
+                dxi, = torch.autograd.grad(a_, xin, g[:, :dims[-1]])
+            dx = torch.zeros_like(x)
+            dx[:, :dims[0]] = dxi
+        return (None, dx, None, None, *grads)
 
 
 def _point_map_graph(rod, handle, y, yh, zh, tf, cut=True):
@@ -146,6 +165,31 @@ def _point_map_graph(rod, handle, y, yh, zh, tf, cut=True):
                          torch.stack([u1, -u2, o, u0], dim=1), torch.stack([u2, u1, -u0, o], dim=1)], dim=1)
     hs = 0.5 * torch.einsum("qij,qj->qi", omega, hq)
     return torch.cat([ps, hs, ns, ms, qs, ws], dim=1), z
+
+
+class _OdePhysicsFunction(torch.autograd.Function):
+    """Physics part of ``ODE_parallel`` with gradients into its inputs (cosserat_ode_torch.py:264-306 lets autograd
+    flow there; no caller of the reference uses it).  Forward: ``kr_ode_batch``.  Backward: vector-Jacobian product of
+    the fp64 graph ``_point_map_graph`` (uncut - ODE_parallel builds R and the quaternion-rate matrix with torch.stack)."""
+
+    @staticmethod
+    def forward(ctx, rod, ys, yhs, zhs, tf):
+        h = rod._native()
+        c = lambda t: t.detach().float().contiguous()
+        dys, z = h.ode_batch(c(ys), c(yhs), c(zhs), c(tf), use_nn=False)
+        ctx.rod = rod
+        ctx.save_for_backward(c(ys), c(yhs), c(zhs), c(tf))
+        return dys, z
+
+    @staticmethod
+    def backward(ctx, g_dys, g_z):
+        rod = ctx.rod
+        leaves = [t.double().requires_grad_(True) for t in ctx.saved_tensors]
+        with torch.enable_grad():
+            ys_g, z_g = _point_map_graph(rod, rod._native(), *leaves, cut=False)
+            grads = torch.autograd.grad([ys_g, z_g], leaves, [g_dys.double(), g_z.double()], allow_unused=True)
+        out = [None if (g is None or not need) else g.float() for g, need in zip(grads, ctx.needs_input_grad[1:])]
+        return (None, *out)
 
 
 class _SweepFunction(torch.autograd.Function):
@@ -407,9 +451,14 @@ class CosseratRodTorch:
         """Batched arc-length derivative, cosserat_ode_torch.py:217-322:
         [Q,19],[Q,19],[Q,6],[Q,3] -> (dys[Q,19], z[Q,6])."""
         h = self._native()
-        c = lambda t: t.detach().float().contiguous()
-        y_, yh_, zh_, tf_ = c(ys), c(yhs), c(zhs), c(tendon_forcess)
-        dys, z = h.ode_batch(y_, yh_, zh_, tf_, use_nn=False)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (ys, yhs, zhs, tendon_forcess)):
+            # gradients into the inputs requested (no reference caller does): same kernels forward, see the Functions
+            y_, yh_, zh_, tf_ = (t.float() for t in (ys, yhs, zhs, tendon_forcess))
+            dys, z = _OdePhysicsFunction.apply(self, y_, yh_, zh_, tf_)
+        else:
+            c = lambda t: t.detach().float().contiguous()
+            y_, yh_, zh_, tf_ = c(ys), c(yhs), c(zhs), c(tendon_forcess)
+            dys, z = h.ode_batch(y_, yh_, zh_, tf_, use_nn=False)
         if self.use_nn:
             parts = [y_, yh_, z, zh_, tf_] if self.nn_input_history else [y_, z, tf_]
             x = torch.cat(parts, dim=1)

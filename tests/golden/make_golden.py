@@ -571,6 +571,35 @@ def gen_tres_grad():
         if use_nn:
             for k, prm in enumerate(rob.nn_models.parameters()):
                 out[f"dparam{k}"] = prm.grad.numpy().copy()
+    # ODE_parallel with autograd into its INPUTS (cosserat_ode_torch.py:217-322; the graph there is intact): rows and
+    # networks of ode_kat.npz / ode_torch_kat.npz, L = sum(dys * Wd) + sum(z * Wz)
+    Q = 48
+    yk, yhk, zhk, tensk = sample_rows(Q, 0)
+    Wd, Wz = rng.standard_normal((Q, 19)).astype(np.float32), rng.standard_normal((Q, 6)).astype(np.float32)
+    out["odep_Wd"], out["odep_Wz"] = Wd, Wz
+    for name, sizes, act, hist in [NN_VARIANTS[0], NN_VARIANTS[1], NN_VARIANTS[5]]:
+        kk = [v[0] for v in NN_VARIANTS].index(name)
+        mlp = orc.make_mlp(sizes, act, seed=100 + kk, history=hist)
+        mlp.weights = [w * 3 for w in mlp.weights]
+        rob = ref_torch.CosseratRodTorch("cpu", 64, nn_input_history=hist)
+        ref_knode.setup_robot(rob, None)
+        rob.nn_models = torch_module_list(mlp)
+        for use_nn in (0, 1):
+            rob.use_nn = bool(use_nn)
+            for prm in rob.nn_models.parameters():
+                prm.grad = None
+            ins = [torch.tensor(a).float().requires_grad_(True) for a in (yk, yhk, zhk)]
+            tfk = (torch.tensor(tensk).float() @ rob.tendon_dirs).detach().requires_grad_(True)
+            dys, zz = rob.ODE_parallel(ins[0], ins[1], ins[2], tfk)
+            L = (dys * torch.tensor(Wd)).sum() + (zz * torch.tensor(Wz)).sum()
+            L.backward()
+            tag = f"odep_{name}_{use_nn}"
+            out[f"{tag}_L"] = np.array(float(L))
+            for nm, tns in zip(("dy", "dyh", "dzh", "dtf"), ins + [tfk]):
+                out[f"{tag}_{nm}"] = tns.grad.numpy().copy()
+            if use_nn:
+                for k, prm in enumerate(rob.nn_models.parameters()):
+                    out[f"{tag}_dparam{k}"] = prm.grad.numpy().copy()
     save("tres_grad", **out)
 
 

@@ -185,6 +185,50 @@ def test_torch_full_sweep_autograd(torch_cuda, use_nn):
     assert rel_l2(G2.grad.cpu().numpy(), np.array(fd)) < 2e-2
 
 
+@pytest.mark.parametrize("name,hist", [("elu64", False), ("hist64", True), ("elu6464", False)])
+@pytest.mark.parametrize("use_nn", [0, 1])
+def test_ode_parallel_input_gradients(torch_cuda, name, hist, use_nn):
+    """ODE_parallel with autograd into its inputs (cosserat_ode_torch.py:217-322): L = sum(dys * Wd) + sum(z * Wz),
+    dL/d(ys, yhs, zhs, tendon forces) and dL/d(MLP parameters) against the reference's autograd (tres_grad.npz)."""
+    torch = torch_cuda
+    import torch.nn as nn
+    from cosserat_ode_torch import CosseratRodTorch
+    from knode import setup_robot
+    k, gg = load_golden("ode_kat"), load_golden("tres_grad")
+    rob = CosseratRodTorch(DEV, 64, nn_input_history=hist)
+    setup_robot(rob, None)
+    mods, i = [], 0
+    while f"mlp_{name}_W{i}" in k.files:
+        W, b = k[f"mlp_{name}_W{i}"], k[f"mlp_{name}_b{i}"]
+        lin = nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            lin.weight.copy_(torch.tensor(W))
+            lin.bias.copy_(torch.tensor(b))
+        mods.append(lin)
+        if f"mlp_{name}_W{i + 1}" in k.files:
+            mods.append(nn.ELU())
+        i += 1
+    rob.nn_models = nn.ModuleList(mods).to(DEV)
+    rob.use_nn = bool(use_nn)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    ins = [t(k[n]).requires_grad_(True) for n in ("y", "yh", "zh")]
+    tf = (t(k["tensions"]) @ rob.tendon_dirs.float().reshape(4, 3)).detach().requires_grad_(True)
+    dys, z = rob.ODE_parallel(ins[0], ins[1], ins[2], tf)
+    L = (dys * t(gg["odep_Wd"])).sum() + (z * t(gg["odep_Wz"])).sum()
+    L.backward()
+    tag = f"odep_{name}_{use_nn}"
+    assert abs(float(L.detach()) - float(gg[f"{tag}_L"])) < 1e-5 * abs(float(gg[f"{tag}_L"]))
+    for nm, tns in zip(("dy", "dyh", "dzh", "dtf"), ins + [tf]):
+        assert rel_l2(tns.grad.cpu().numpy(), gg[f"{tag}_{nm}"]) < 2e-5, nm
+    if use_nn:
+        for j, prm in enumerate(rob.nn_models.parameters()):
+            assert rel_l2(prm.grad.cpu().numpy(), gg[f"{tag}_dparam{j}"]) < 2e-4, j
+    # without gradients requested the plain kernel path runs and gives the same values
+    with torch.no_grad():
+        d2, z2 = rob.ODE_parallel(*[x.detach() for x in ins], tf.detach())
+    assert torch.equal(d2, dys.detach()) and torch.equal(z2, z.detach())
+
+
 # ---------------------------------------------------------------------------
 # cfg5: N = 400
 # ---------------------------------------------------------------------------
