@@ -2,23 +2,33 @@
 // (reference: CosseratRodTorch.forward, cosserat_ode_torch.py:131-134, and loss.backward() of
 // physics_train.py:290,394 restricted to the MLP parameters).
 //
-// One wavefront owns blocks of 64 rows.  Everything is expressed in the transposed form
+// One wavefront owns blocks of 16 FT (= 32) rows.  Everything is expressed in the transposed form
 // [units x samples] so that an MFMA accumulator tile (v_mfma_f32_16x16x4_f32: lane l holds column
 // sample l&15, rows 4*(l>>4)+r) is directly the B operand of the next product:
 //
 //   forward   Z1 = W1 X^T + b1, A1 = act(Z1);  Z2 = W2 A1 + b2, A2 = act(Z2);  OUT = W3 A2 + b3
 //   backward  dZ2 = (W3^T dOUT) * act'(Z2);  dZ1 = (W2^T dZ2) * act'(Z1)          (chain in registers)
-//             dW3 += dOUT A2^T, dW2 += dZ2 A1^T, dW1 += dZ1 X^T                   (contraction over the 64
-//             samples: both operands go through an LDS tile [sample][unit], the products accumulate in
-//             registers over all row blocks of the wave and are added to HBM once, with float atomics)
+//             dW3 += dOUT A2^T, dW2 += dZ2 A1^T, dW1 += dZ1 X^T                   (contractions over the samples of
+//             a block: both operands go through transposed LDS tiles T[unit][position], see "backward" below)
 //
-// The backward kernel recomputes the hidden activations instead of reading them back (the forward
-// kernel stores nothing but OUT), so a training step moves X, OUT and dOUT through HBM exactly once:
-// 3 x 128 B per row.  Weights are re-packed into MFMA fragment order on the device at every call
-// (they are torch parameters that change every optimizer step; ~30 KB).
-// Shapes served: in(<=32) -> H1 -> out(<=32) with any H1 (streamed in chunks of 64 units) and
-// in -> H1 -> H2 -> out with H1, H2 <= 64; one activation for all hidden layers.  Other networks
-// use the generic GEMM path of kr_train.hip.
+// Kernels (all __launch_bounds__(64, 2): two wavefronts per SIMD, so that the matrix-pipe phases of one overlap
+// the vector / LDS phases of the other):
+//   mlp_fwd_fused_kernel   all layers in registers; three-layer networks also dump A1 and A2 of every row block as raw
+//                          register images ([block][unit tile][sample tile][lane] x 16 B: coalesced, and already the
+//                          operand layout of the consumer)
+//   mlp_bwd3a_kernel       three layers, pass 1: dW3, db3, dZ2 (dumped the same way), from dOUT and the A2 image
+//   mlp_bwd3b_kernel       pass 2: dW2, db2, dZ1, dW1, db1 from the dZ2 and A1 images and X
+//   mlp_bwd2_kernel        two layers (any hidden width, streamed in chunks of 64 units): recomputes the hidden chunk
+//   reduce_slabs_kernel    weight gradients accumulate in registers over all row blocks of a wave and leave it ONCE, as
+//                          plain stores into the wave's slab [wave][all parameters]; this kernel sums the slabs
+//                          (32 groups per parameter, one float atomic each).  Float atomics from ~1000 waves into the
+//                          same 10 k addresses serialised in L2 and cost more than the arithmetic (bwd3a 190 -> 59 us).
+// Splitting the three-layer backward in two and dumping activations instead of recomputing them is what lets every
+// kernel fit 256 registers (2 waves per SIMD) without spilling; HBM is otherwise idle in these kernels.
+// Weights are re-packed into MFMA fragment order on the device at every call (pack_all_kernel, one launch; they are
+// torch parameters that change every optimizer step; ~30 KB).
+// Shapes served: in(<=32) -> H1 -> out(<=32) with any H1 and in -> H1 -> H2 -> out with H1, H2 <= 64; one activation
+// for all hidden layers.  Other networks use the generic GEMM path of kr_train.hip.
 #include <type_traits>
 
 #include "kr_internal.hpp"

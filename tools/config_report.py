@@ -38,7 +38,11 @@ def timed_sim(r, B, T, dtype, seed, warm=60):
 print("cfg1  single rod, N=20, 200 steps, constant tensions (reference fixture sim_cfg1)")
 g = G("sim_cfg1"); r = robot(20)
 t0 = time.perf_counter(); tr = simulate(r, g["ctl"]); el = time.perf_counter() - t0
-print(f"      tip rel L2 vs reference {rel(tr[:, :3, -1], g['tip']):.2e}; knode.simulate wall {el*1e3:.1f} ms for 200 steps (incl. host<->device copies)")
+ws = []
+for _ in range(5):
+    t0 = time.perf_counter(); tr = simulate(r, g["ctl"]); ws.append(time.perf_counter() - t0)
+print(f"      tip rel L2 vs reference {rel(tr[:, :3, -1], g['tip']):.2e}; knode.simulate wall, 200 steps incl. host<->device copies: "
+      f"first call {el*1e3:.1f} ms (library load, handle, allocations), then {np.median(ws)*1e3:.2f} ms = {np.median(ws)/200*1e3:.4f} ms/step")
 
 print("cfg2  B=256, N=100, forward only")
 g = G("sim_n100"); r = robot(100)
