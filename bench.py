@@ -187,7 +187,7 @@ def main():
     robot2.compute_intermediate_terms()
     h2 = robot2._native()
 
-    def run_cold(T, dt=None):
+    def run_cold(T, dt=None, scheme=0):
         """T steps from the straight rod with no predictor hand-over: (seconds, unconverged rod-steps)."""
         dt = dt or tdt
         c = torch.as_tensor(rank_controls(B, world, rank, T, robot.del_t), device=dev).to(dt).contiguous()
@@ -198,24 +198,35 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        h2.simulate(c, st, g0, ring=True, status=stat)
+        h2.simulate(c, st, g0, ring=True, status=stat, scheme=scheme)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3, int((stat != 0).sum())
 
-    # Clock ramp, not part of the untimed steps: an idle MI355X needs a few hundred ms of full load before its
-    # shader clock settles, and drops it again within milliseconds of light load.  The ramp runs the persistent
-    # solver in the OTHER precision on scratch copies of the problem (a different kernel instantiation, so that in a
-    # rocprofv3 trace of `bench.py --no-cpu` the timed kernel appears exactly once: the K timed steps); the untimed
-    # steps of the trajectory go through the one-launch-per-step form for the same reason.
-    ramp_dt = torch.float32 if args.dtype == "f64" else torch.float64
+    # Clock ramp, not part of the untimed steps.  The shader clock of an MI355X under this fp64 load settles over
+    # SECONDS of accumulated load, not milliseconds (tools/clock_probe*.py: the same 20-step launch, every rod at
+    # exactly 2 sweeps per step and 84 k ticks per step each time, takes 46 us per step in a process that has just
+    # started and 36 us after ~2 s of fp64 work; an fp32 ramp warms less).  The ramp runs the persistent solver with
+    # RK4 sweeps in the precision of the measurement on scratch copies of the problem: the same instruction mix, but a
+    # different kernel instantiation, so that in a rocprofv3 trace of `bench.py --no-cpu` the timed kernel appears
+    # exactly once (the K timed steps); the untimed steps of the trajectory go through the one-launch-per-step form
+    # for the same reason.
     h.set_option("keep_predictor", 0)
     persistent_default = h.get_option("persistent")
 
+    ramp_ctl = torch.as_tensor(rank_controls(B, world, rank, 100, robot.del_t), device=dev).to(tdt).contiguous()
+    ramp_st = h2.new_state(B, tdt, n_slots=3)
+    ramp_g = torch.zeros((B, 6), dtype=tdt, device=dev)
+
     def ramp(seconds):
-        t_ramp = time.perf_counter()
-        while time.perf_counter() - t_ramp < seconds:
-            run_cold(200, ramp_dt)
+        """Queues launches without waiting in between, so that the GPU goes from the last one straight into whatever
+        follows the next synchronize()."""
+        n = max(1, int(seconds / 0.012))  # one 100-step RK4 launch of this batch takes ~12 ms
+        for _ in range(n):
+            h2.init_straight(ramp_st[0])
+            ramp_g.zero_()
+            h2.simulate(ramp_ctl, ramp_st, ramp_g, ring=True, scheme=1)  # KR_RK4
+        torch.cuda.synchronize()
 
     ramp(0.5)
     cold = None
@@ -226,11 +237,16 @@ def main():
             cold[f"T{T}"] = {"value": round(B * T / secs, 1), "ms_per_step": round(secs / T * 1e3, 4), "unconverged": bad}
 
     # the untimed and the timed steps are one trajectory advanced by two calls: the second call resumes the
-    # start-value predictor of the first (option "keep_predictor")
+    # start-value predictor of the first (option "keep_predictor").  What precedes the timed launch sets its clock
+    # (tools/clock_probe3.py, 20-step launch: 35 us per step right after light launches, 36-37 after 1 s of full load,
+    # 40 after 3 s of it, 42 after 20 ms of idling): a short ramp, then the untimed steps (one launch per step: light),
+    # then the timed launch with nothing but the contract's barrier + synchronize in between.
     h.set_option("persistent", 0)
     h.set_option("keep_predictor", 1)
     pre_states = h.new_state(B, tdt, n_slots=pre + 1) if pre else None
     states = h.new_state(B, tdt, n_slots=3)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ramp(0.3)  # (on the second handle: the predictor image of `h` is not touched)
     if pre:
         h.init_straight(pre_states[0])
         h.simulate(ctl_pre, pre_states, G, tip=tip_pre)
@@ -240,11 +256,8 @@ def main():
         h.init_straight(states[0])
         prev_init = None
     h.set_option("persistent", persistent_default)
-    ramp(0.25)  # (on the second handle: the predictor image the untimed steps left on `h` is not touched)
-    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     ev0.record()

@@ -1341,9 +1341,19 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T>
   unsigned long long t_begin, tp;
   KR_STAMP(t_begin);
 #endif
+#ifdef KR_MS_STAMPS
+  // clock trace (tools/clock_probe.py): the host asks for it by putting a magic number into the unused slot 15 of the
+  // last rod's row and has then allocated 2 T more slots behind the B rows; rod 0 records, at the start of every
+  // step, the shader-clock counter and the constant 100 MHz counter
+  const bool clock_trace = A.dbg && rod == 0 && A.dbg[(A.B - 1) * 24 + 15] == 0xC10CULL;
+#endif
   for (int64_t t = 0; t < A.T_steps; ++t) {
 #ifdef KR_MS_STAMPS
     KR_STAMP(tp);
+    if (clock_trace && lane == 0) {
+      A.dbg[A.B * 24 + 2 * t] = tp;
+      A.dbg[A.B * 24 + 2 * t + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
     // ---- history records from c12 (newest) and regP (the one before) ----------
 #pragma unroll

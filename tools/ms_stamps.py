@@ -8,7 +8,7 @@ import numpy as np, torch
 import cosserat_oracle as orc, krod_native as kn
 from cosserat_ode import CosseratRod
 from knode import setup_robot
-B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 100, 120
+B, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 100, int(os.environ.get("KR_STAMP_T", "120"))
 NN = len(sys.argv) > 2 and sys.argv[2] == "nn"   # MLP 28 -> 64 -> 64 -> 25 inside the sweeps
 if NN: T = 40
 dev = "cuda:0"; dt = torch.float64
