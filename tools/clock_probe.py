@@ -37,6 +37,9 @@ for K in (20, 20, 100, 1000, 20):
     tot, its = d[:, 0], d[:, 4]
     print(f"K={K:5d}: {ms*1e3/K:6.1f} us/step (event) | ticks/step mean {tot.mean()/K:8.0f} max {tot.max()/K:8.0f} | sweeps/step mean {its.mean()/K:.3f} max {its.max()/K:.3f} | "
           f"max ticks / event time = {tot.max()/(ms*1e3):7.1f} ticks/us")
+    qn = dbg[:B * 24].reshape(B, 24)[:, 15].cpu().numpy().view(np.float64)
+    print(f"      per step: sweep {d[:,1].mean()/K:.0f} algebra {d[:,2].mean()/K:.0f} (hand-over {d[:,8].mean()/K:.0f} chain {d[:,9].mean()/K:.0f} solve {d[:,10].mean()/K:.0f} rest {d[:,11].mean()/K:.0f}) "
+          f"history+guess {d[:,3].mean()/K:.0f}; residual-test acceptances per step {qn.mean()/K:.3f}; slowest rod: sweep {d[:,1].max()/K:.0f} algebra {d[:,2].max()/K:.0f}")
     if K >= 2:
         dc, dr = np.diff(tr[:, 0]), np.diff(tr[:, 1])           # shader cycles and 10 ns units per step of rod 0
         mhz = dc / (dr * 0.01)

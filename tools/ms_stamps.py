@@ -36,6 +36,7 @@ for pred in (7, 8):
     print(f"pred={pred}: wall {el/T*1e6:.1f} us/step; s_memtime ticks per step: total mean {tot.mean()/T:.0f} max {tot.max()/T:.0f} | "
           f"sweep {sw.mean()/T:.0f} alg {al.mean()/T:.0f} prep {pr.mean()/T:.0f} | its/step mean {its.mean()/T:.2f} max {its.max()/T:.2f} | "
           f"per-iteration sweep {sw.sum()/its.sum():.0f} alg {al.sum()/its.sum():.0f} ticks; tick rate {tot.max()/el/1e6:.1f} MHz")
+    print(f"   sweeps accepted by the residual test, per step: {dbg[:, 15].cpu().numpy().view(np.float64).mean()/T:.3f}")
     print(f"   algebra per iteration: hand-over {d[:,8].sum()/its.sum():.0f} chain {d[:,9].sum()/its.sum():.0f} solve {d[:,10].sum()/its.sum():.0f} update {d[:,11].sum()/its.sum():.0f}")
     dn = dbg[:, 5:8].cpu().numpy().view(np.float64)
     its_rod = its / T
