@@ -648,12 +648,11 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
     }
     // rows 3..18: lanes 0..15 (+16 k) own (row 3 + (lane & 15)) of the local unknown k
     T updR[4], xsR[4];
-    int ng = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       updR[k] = T(0); xsR[k] = T(0);
       const int g = wave == 0 ? 1 + k : R.g0 + k;       // unknown states owned by this wavefront
-      const bool own = (wave == 0 ? k < 3 : k < 3) && g < P && (lane >> 4) == k;
+      const bool own = k < 3 && g < P && (lane >> 4) == k;
       if (own) {
         const int rr = 3 + (lane & 15);
         xsR[k] = Xs[g * 19 + rr];
@@ -669,7 +668,6 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       updG = L.dY[0 * 19 + 7 + k];
       dnf = fmaxf(dnf, update_ratio(updG, xsG));
     }
-    (void)ng;
     dnf = msw_max<W>(dnf, redf, wave, lane);
     const bool finite = dnf <= 3.0e38f;
     const T dn = (T)dnf;

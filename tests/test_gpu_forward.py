@@ -30,7 +30,7 @@ def torch_cuda():
     return torch
 
 
-from gpu_helpers import MODES, assert_path, inject, make_robot, require_path, set_mode_env  # noqa: E402
+from gpu_helpers import MODES, assert_path, expected_path, inject, make_robot, require_path, set_mode_env  # noqa: E402
 
 
 @pytest.fixture(autouse=True, params=MODES)
@@ -393,6 +393,49 @@ def test_adaptive_predictor_on_rough_inputs(torch_cuda, shooting_mode, kind):
     for t in (1, 29, 31, 35, 61, T):  # all solves stop at |update| <= 1e-8: agreement at that level
         assert rel_l2(outs[0][t], outs[2][t]) < 1e-7
         assert rel_l2(outs[1][t], outs[2][t]) < 1e-7
+
+
+@pytest.mark.parametrize("N,dtype", [(20, "f64"), (20, "f32"), (6, "f64")])
+def test_step_batch_matches_simulate(torch_cuda, shooting_mode, N, dtype):
+    """kr_step_batch - the loop body of knode.simulate (knode.py:70-100) on its own: T steps taken one call at a time
+    (first with prev = cur as knode.py:65-66, then with one and two older states for the time extrapolation of the
+    start values) reach the states kr_simulate_batch stores, and both equal the oracle's."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    if shooting_mode == "persistent":
+        pytest.skip("kr_step_batch is one launch per call: same kernels as the 'single' / 'multi' parametrisations")
+    want = expected_path(shooting_mode, N)
+    r = make_robot(None, N)
+    h = r._native()
+    dt = torch.float64 if dtype == "f64" else torch.float32
+    B, T = 5, 9
+    ctl = orc.batch_sine_controls(B, T, r.del_t, 99)
+    ctl_t = torch.as_tensor(ctl, device="cuda:0").to(dt).contiguous()
+    ref = h.new_state(B, dt, n_slots=T + 1)
+    h.init_straight(ref[0])
+    Gr = torch.zeros((B, 6), dtype=dt, device="cuda:0")
+    h.set_option("persistent", 0)
+    h.simulate(ctl_t, ref, Gr)
+    for use_prev2 in (False, True):
+        st = h.new_state(B, dt, n_slots=T + 1)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=dt, device="cuda:0")
+        status = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
+        iters = torch.zeros((B,), dtype=torch.int32, device="cuda:0")
+        for t in range(T):
+            prev = st[t - 1] if t else st[0]
+            prev2 = st[t - 2] if (use_prev2 and t >= 2) else None
+            h.step(prev, st[t], st[t + 1], G, ctl_t[:, t].contiguous(), status=status, iters=iters, prev2=prev2)
+            assert_path(h, want)
+            assert int((status != 0).sum()) == 0 and int(iters.min()) >= 1
+        scale = float(ref[T].abs().max())
+        tol = (1e-9 if dtype == "f64" else 2e-4) * scale
+        assert float((st[T] - ref[T]).abs().max()) < tol
+        assert float((G - Gr).abs().max()) < (1e-8 if dtype == "f64" else 1e-3) * max(1.0, float(Gr.abs().max()))
+    D = orc.params_for(None, N).derived()
+    tip = orc.simulate(D, np.vstack([ctl[2], ctl[2][-1:]]), solver="newton")[1:, :3, -1]
+    got = torch.stack([h.tip(st[t + 1])[2] for t in range(T)]).double().cpu().numpy()
+    assert rel_l2(got, tip) < (1e-8 if dtype == "f64" else 1e-5)
 
 
 def test_error_paths(torch_cuda, shooting_mode):

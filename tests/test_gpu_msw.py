@@ -150,6 +150,41 @@ def test_batch_properties(torch_cuda, waves):
         assert bad == 0 and rel_l2(tips[torch.float64][b], tip_c) < 1e-8
 
 
+def test_step_batch(torch_cuda, waves):
+    """kr_step_batch on a long rod (the branch of the kernel that extrapolates its start values from the states it
+    is handed, with zero, one and two older states): same states as kr_simulate_batch, tips equal the C oracle's."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    import cosserat_oracle_c as oc
+    r = make_robot(None, 400)
+    h = r._native()
+    dt = torch.float64
+    B, T = 3, 6
+    ctl = np.stack([np.array(orc.calc_controls("sine", P, r.del_t, T)) for P in (0.5, 1.0, 3.0)])
+    ctl_t = torch.as_tensor(ctl, device=DEV).contiguous()
+    ref = h.new_state(B, dt, n_slots=T + 1)
+    h.init_straight(ref[0])
+    h.simulate(ctl_t, ref, torch.zeros((B, 6), dtype=dt, device=DEV))
+    assert_path(h, 1, waves)
+    for use_prev2 in (False, True):
+        st = h.new_state(B, dt, n_slots=T + 1)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=dt, device=DEV)
+        status = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+        for t in range(T):
+            prev = st[t - 1] if t else st[0]
+            prev2 = st[t - 2] if (use_prev2 and t >= 2) else None
+            h.step(prev, st[t], st[t + 1], G, ctl_t[:, t].contiguous(), status=status, prev2=prev2)
+            assert_path(h, 1, waves)
+            assert int((status != 0).sum()) == 0
+        # (two Newton runs from different start values: equal to within the stopping tolerance 1e-8, not to rounding)
+        assert float((st[T] - ref[T]).abs().max()) < 1e-8 * float(ref[T].abs().max())
+    for b in range(B):
+        tip_c, _, bad = oc.simulate(orc.params_for(None, 400), ctl[b])
+        got = torch.stack([h.tip(st[t + 1])[b] for t in range(T)]).cpu().numpy()
+        assert bad == 0 and rel_l2(got, tip_c) < 1e-8
+
+
 def test_auto_choice(torch_cuda, monkeypatch):
     """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512, one beyond;
     N = 100 (served by the persistent kernel) never takes this path."""
