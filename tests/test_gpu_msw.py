@@ -185,6 +185,29 @@ def test_step_batch(torch_cuda, waves):
         assert bad == 0 and rel_l2(got, tip_c) < 1e-8
 
 
+def test_iteration_cap_is_reported(torch_cuda, waves):
+    """A step that runs into the iteration cap ends (every wavefront of the workgroup leaves the loop together), streams
+    its last iterate and reports status 1; with enough iterations the same inputs converge."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    r = make_robot(None, 150)
+    h = r._native()
+    dt = torch.float64
+    ctl = torch.as_tensor(np.array(orc.calc_controls("step", 3.0, r.del_t, 4), dtype=np.float64)[None], device=DEV).contiguous()
+    for maxit, ok in ((1, False), (30, True)):
+        st = h.new_state(1, dt, n_slots=5)
+        h.init_straight(st[0])
+        status = torch.full((1, 4), -1, dtype=torch.int32, device=DEV)
+        h.simulate(ctl, st, torch.zeros((1, 6), dtype=dt, device=DEV), status=status, maxit=maxit)
+        torch.cuda.synchronize()
+        assert_path(h, 1, waves)
+        assert bool(torch.isfinite(st).all())
+        if ok:
+            assert int((status != 0).sum()) == 0
+        else:
+            assert int((status == 1).sum()) >= 1 and int((status > 1).sum()) == 0
+
+
 def test_auto_choice(torch_cuda, monkeypatch):
     """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512, one beyond;
     N = 100 (served by the persistent kernel) never takes this path."""
