@@ -290,6 +290,16 @@ int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, cons
                          const float* target_rows, double denom, float* pred, float* loss, float* dout,
                          void* stream);
 
+/* kr_mlp_forward followed by kr_loss_rows_fwd_bwd (pred = NULL) over the Q = S*K rows of a training set in ONE
+ * call - physics_train.py:250-259 / 345-352 from the MLP inputs to the loss and d loss / d out.  Where the fused
+ * kernels serve the network the loss runs in the epilogue of the forward kernel (the MLP outputs never reach HBM);
+ * otherwise the two kernels run back to back through `out` ([Q][32] scratch, always required).  Same meaning of
+ * loss / dout / the option "mlp_grad_accumulate" as kr_loss_rows_fwd_bwd; ws as for kr_mlp_forward. */
+int kr_mlp_forward_loss(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* dims, const int32_t* acts,
+                        const float* const* W, const float* const* b, const float* x, int in_pad, const float* base,
+                        const float* target_rows, double denom, float* out, float* loss, float* dout, void* ws,
+                        void* stream);
+
 /* Full-state estimate from measured poses, knode_cosserat_realworld/estimate_state.py:158-242 (with compute_v_u
  * :48-95, compute_angular_velocities :97-123, compute_internal_forces_and_moments :126-156): data[T][7][N]
  * (positions, quaternions at the handle's N grid points), tensions[T][4] -> est[T][25][N], fp64, device pointers.

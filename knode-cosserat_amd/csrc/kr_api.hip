@@ -431,6 +431,7 @@ int kr_destroy(kr_handle* h) {
   free_mlp(h);
   if (h->ws) (void)hipFree(h->ws);
   if (h->pred_buf) (void)hipFree(h->pred_buf);
+  if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   delete h;
   return KR_OK;
 }

@@ -81,6 +81,7 @@ struct kr_handle {
                              // 1 one multiple-shooting launch per step, 2 one persistent launch for all steps
   int waves_per_rod = 0;     // per-step launches: wavefronts that share a rod (kr_msw_impl.hpp): 0 auto, 1, 2 or 4
   int last_waves_per_rod = 1;  // what the last step launch used
+  void* loss_scratch = nullptr;  // per-workgroup loss partials of the fused forward + loss kernel
   void* dbg = nullptr;       // diagnostic cycle-counter buffer (kr_debug_buffer)
   int fused_mlp = 1;         // training: fused MFMA forward/backward kernels (kr_mlp_fused.hip) when the shape allows
   int mfma_mlp = 1;          // evaluate the in-sweep MLP on the matrix cores when its shape allows
@@ -181,8 +182,19 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
 // kr_mlp_fused.hip: fused fp32 MLP forward / backward for training
 bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad);
 size_t fused_ws_bytes(int n_layers, const int32_t* dims, int64_t Q);
+// loss fused into the epilogue of the forward kernel (kr_mlp_forward_loss); all device pointers
+struct FusedLoss {
+  const float* base;         // [Q][25] parameter-free part of the prediction
+  const float* target_rows;  // [Q][25]
+  float* dout;               // [Q][32] gradient with respect to the MLP outputs
+  float* loss;               // the four-term loss is ADDED here
+  void* scratch;             // 4096 floats of the handle: per-workgroup partials
+  float ds, inv_denom;
+  int K;
+};
 int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
-                      const float* const* b, const float* x, float* out, void* ws, hipStream_t s);
+                      const float* const* b, const float* x, float* out, void* ws, hipStream_t s,
+                      const FusedLoss* fl = nullptr);
 int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
                        const float* x, const float* dout, void* ws, float* const* dW, float* const* db, hipStream_t s);
 

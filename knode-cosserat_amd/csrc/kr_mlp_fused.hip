@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "kr_internal.hpp"
+#include "kr_loss_device.hpp"
 
 namespace kr {
 
@@ -49,6 +50,7 @@ typedef float fvT __attribute__((ext_vector_type(FT)));  // the FT samples a lan
 constexpr int FPD = 3;       // prefetch distance of weight fragments, in k-steps
 constexpr int F_LDX = 32;    // row length of the X / dOUT tiles
 constexpr int F_LDH = 64;    // row length of the hidden tiles
+constexpr int F_LDO = 36;    // pitch of the forward kernel's output tile
 
 struct FChunk {
   f4 a[4][FT];  // [unit tile][sample tile]
@@ -266,12 +268,13 @@ __device__ __forceinline__ void load_bops(float (&b)[FT][8], const float* tile, 
 }
 
 // rows [row0, row0 + FR) of a row-major [Q][32] array -> LDS tile (zero beyond Q); 64 / FR lanes share a row
+template <int PITCH = F_LDX>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ g, int64_t row0, int64_t Q, float* tile, int lane) {
   constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;
   const int rl = lane % FR, part = lane / FR;
   const int64_t row = row0 + rl;
   const f4* src = reinterpret_cast<const f4*>(g + row * F_LDX) + part * NV;
-  f4* dst = reinterpret_cast<f4*>(tile + rl * F_LDX) + part * NV;
+  f4* dst = reinterpret_cast<f4*>(tile + rl * PITCH) + part * NV;
 #pragma unroll
   for (int c = 0; c < NV; ++c) dst[c] = row < Q ? src[c] : f4{0.f, 0.f, 0.f, 0.f};
 }
@@ -315,22 +318,60 @@ struct FusedArgs {
   float* a1d;            // three-layer networks: hidden activations A1, A2 of every row block as register images, written
   float* a2d;            // by the forward kernel and read by the backward passes (HBM is idle here, the matrix pipe is not)
   float* dz2;            // three-layer backward: dZ2 of every row block between the two passes, [blocks][16][64] x 16 bytes
+  // forward with the loss fused into its epilogue (kr_mlp_forward_loss): parameter-free part of the prediction and
+  // target values per row [Q][25], gradient out [Q][32]; lbase == nullptr: plain forward
+  const float* lbase;
+  const float* ltarget;
+  float* ldout;
+  float* lpart;          // one loss partial per workgroup (summed by loss_partials_kernel: one atomic per workgroup on
+                         // a single address serialises at the memory side - 4096 of them cost 16 us; a device-scope
+                         // fence per workgroup for an in-kernel arrival count writes the L2 back each time - 180 us)
+  float lds;             // arc-length step: pred = base + [ds out[:19], out[19:]]
+  LossWeights lw;
 };
 
 // ---- forward -------------------------------------------------------------------------------------------
 template <int ACT>
 __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A) {
-  __shared__ __attribute__((aligned(16))) float tx[FR * F_LDX];
+  __shared__ __attribute__((aligned(16))) float tx[FR * F_LDO];
+  __shared__ __attribute__((aligned(16))) float tbt[2 * FR * 25];  // fused loss: base rows, target rows of the block
   const int lane = threadIdx.x;
   const int64_t nblk = (A.Q + FR - 1) / FR;
+  const bool with_loss = A.lbase != nullptr;
+  float loss_part = 0.f;
   for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
-    stage_rows(A.x, rb * FR, A.Q, tx, lane);
+    stage_rows<F_LDO>(A.x, rb * FR, A.Q, tx, lane);  // (pitch 36: the operand reads below hit 2 banks, not 16)
+    // fused loss: the block's base and target rows (FR x 25 contiguous floats of each array; a row block starts at a
+    // multiple of 3200 bytes) are requested now, as 16-byte pieces into registers, and go to LDS only when the
+    // epilogue needs them - their latency hides behind the layers
+    constexpr int LNV = (FR * 25 / 4 + 63) / 64;
+    f4 lvb[LNV], lvt[LNV];
+    if (with_loss) {
+      const int64_t e0 = rb * FR * 25, eN = A.Q * 25;
+      const f4* sb = reinterpret_cast<const f4*>(A.lbase + e0);
+      const f4* st = reinterpret_cast<const f4*>(A.ltarget + e0);
+#pragma unroll
+      for (int q = 0; q < LNV; ++q) {
+        const int i = lane + 64 * q;
+        lvb[q] = f4{0.f, 0.f, 0.f, 0.f};
+        lvt[q] = f4{1.f, 0.f, 0.f, 0.f};
+        if (i < FR * 25 / 4) {
+          if (e0 + 4 * i + 3 < eN) {
+            lvb[q] = sb[i];
+            lvt[q] = st[i];
+          } else {
+            for (int c = 0; c < 4; ++c)
+              if (e0 + 4 * i + c < eN) { lvb[q][c] = A.lbase[e0 + 4 * i + c]; lvt[q][c] = A.ltarget[e0 + 4 * i + c]; }
+          }
+        }
+      }
+    }
     fsync();
     float bin[FT][8];
 #pragma unroll
     for (int s = 0; s < FT; ++s)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) bin[s][k] = tx[(16 * s + (lane & 15)) * F_LDX + 4 * k + (lane >> 4)];
+      for (int k = 0; k < 8; ++k) bin[s][k] = tx[(16 * s + (lane & 15)) * F_LDO + 4 * k + (lane >> 4)];
     f4 oacc[2][FT];
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -361,6 +402,8 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
       facc<2, 16>(oacc, A.wf[2], A.ks[2], 0, 0, lane, [&](int s, int k) { return h2.a[k >> 2][s][k & 3]; });
     }
     fsync();
+    // outputs -> row-major tile (pitch F_LDO: one lane reads a whole row below; 36 keeps the rows 16-byte aligned and
+    // spreads them over 8 banks instead of 1)
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -368,22 +411,83 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int u = 16 * o + 4 * (lane >> 4) + r;
-          tx[(16 * s + (lane & 15)) * F_LDX + u] = u < A.nout ? oacc[o][s][r] : 0.f;
+          tx[(16 * s + (lane & 15)) * F_LDO + u] = u < A.nout ? oacc[o][s][r] : 0.f;
         }
+    if (with_loss) {
+#pragma unroll
+      for (int q = 0; q < LNV; ++q) {
+        const int i = lane + 64 * q;
+        if (i < FR * 25 / 4) {
+          reinterpret_cast<f4*>(tbt)[i] = lvb[q];
+          reinterpret_cast<f4*>(tbt + FR * 25)[i] = lvt[q];
+        }
+      }
+    }
     fsync();
+    if (with_loss) {
+      // one row per lane (lanes 0 .. FR-1): prediction, four-term loss, gradient with respect to the outputs (written
+      // over them).  The upper half of the wave is idle here, so it takes one of the two quaternion_to_euler calls
+      // of a row: lane FR + r converts the target quaternion of row r while lane r converts the predicted one.
+      static_assert(FR == 32, "lane <-> row map of the loss epilogue");
+      const int rl = lane & (FR - 1);
+      const bool valid = rb * FR + rl < A.Q;
+      float e[3] = {0.f, 0.f, 0.f};
+      {
+        float q[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          q[c] = lane < FR ? tbt[rl * 25 + 3 + c] + A.lds * tx[rl * F_LDO + 3 + c] : tbt[FR * 25 + rl * 25 + 3 + c];
+        if (!valid) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; }
+        q2e(q, e);
+      }
+      float eo[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) eo[c] = __shfl_xor(e[c], FR, 64);
+      if (lane < FR && valid) {
+        float p[25], tgv[25], g[25];
+#pragma unroll
+        for (int r = 0; r < 25; ++r) {
+          p[r] = tbt[lane * 25 + r] + (r < 19 ? A.lds : 1.f) * tx[lane * F_LDO + r];
+          tgv[r] = tbt[FR * 25 + lane * 25 + r];
+        }
+        loss_part += loss_row_angles(p, tgv, e, eo, A.lw, g);
+#pragma unroll
+        for (int r = 0; r < 25; ++r) tx[lane * F_LDO + r] = (r < 19 ? A.lds : 1.f) * g[r];
+      }
+      fsync();
+    }
     {
       constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;  // lanes per row, 16-byte pieces per lane
       const int rl = lane % FR, part = lane / FR;
       const int64_t row = rb * FR + rl;
       if (row < A.Q) {
-        const f4* src = reinterpret_cast<const f4*>(tx + rl * F_LDX) + part * NV;
-        f4* dst = reinterpret_cast<f4*>(A.out + row * F_LDX) + part * NV;
+        const f4* src = reinterpret_cast<const f4*>(tx + rl * F_LDO) + part * NV;
+        f4* dst = reinterpret_cast<f4*>((with_loss ? A.ldout : A.out) + row * F_LDX) + part * NV;
 #pragma unroll
         for (int c = 0; c < NV; ++c) dst[c] = src[c];
       }
     }
     fsync();
   }
+  if (with_loss) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) loss_part += __shfl_xor(loss_part, m, 64);
+    if (lane == 0) A.lpart[blockIdx.x] = loss_part;
+  }
+}
+
+// sum of the per-workgroup loss partials of a fused forward + loss launch, added to *loss
+__global__ __launch_bounds__(256) void loss_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ loss) {
+  __shared__ float red[256];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) v += part[i];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss, red[0]);
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
@@ -750,9 +854,15 @@ static void launch_by_act(int act, K&& fn) {
 }
 
 int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
-                      const float* const* b, const float* x, float* out, void* ws, hipStream_t s) {
+                      const float* const* b, const float* x, float* out, void* ws, hipStream_t s,
+                      const FusedLoss* fl) {
   FusedArgs A{};
   A.Q = Q; A.x = x; A.out = out;
+  if (fl) {
+    A.lbase = fl->base; A.ltarget = fl->target_rows; A.ldout = fl->dout; A.lds = fl->ds;
+    A.lw = loss_weights(fl->inv_denom, fl->K);
+    A.lpart = static_cast<float*>(fl->scratch);
+  }
   int rc = fused_pack(A, n_layers, dims, W, b, static_cast<float*>(ws), true, s);
   if (rc) return rc;
   const int64_t nblk = (Q + FR - 1) / FR;
@@ -766,6 +876,10 @@ int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_
     hipLaunchKernelGGL((mlp_fwd_fused_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
   });
   KR_HIP(hipGetLastError());
+  if (fl) {
+    hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, A.lpart, grid, fl->loss);
+    KR_HIP(hipGetLastError());
+  }
   return KR_OK;
 }
 

@@ -18,6 +18,7 @@
 #include <cmath>
 
 #include "kr_internal.hpp"
+#include "kr_loss_device.hpp"
 
 namespace kr {
 
@@ -261,45 +262,6 @@ __global__ void gather_targets_kernel(int N, int64_t S, int K, const float* __re
 // ---------------------------------------------------------------------------
 // T4: prediction + four-term loss + gradient w.r.t. the MLP output
 // ---------------------------------------------------------------------------
-// quaternion_to_euler of Utils/transformations.py:3-31 and its Jacobian-transpose product
-__device__ __forceinline__ void q2e(const float q[4], float e[3]) {
-  const float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
-  e[0] = atan2f(2.f * (w * y + x * z), 1.f - 2.f * (y * y + z * z));
-  e[1] = asinf(fminf(fmaxf(2.f * (w * z - x * y), -1.f), 1.f));
-  e[2] = atan2f(2.f * (w * x + y * z), 1.f - 2.f * (x * x + z * z));
-}
-__device__ __forceinline__ void q2e_vjp(const float q[4], const float ge[3], float gq[4]) {
-  const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const float inv = 1.f / nrm;
-  const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
-  float gn[4] = {0.f, 0.f, 0.f, 0.f};  // gradient w.r.t. the normalised quaternion (w, x, y, z)
-  {  // roll = atan2(a, b)
-    const float a = 2.f * (w * y + x * z), b = 1.f - 2.f * (y * y + z * z);
-    const float den = a * a + b * b;
-    const float ga = ge[0] * b / den, gb = -ge[0] * a / den;
-    gn[0] += ga * 2.f * y; gn[1] += ga * 2.f * z; gn[2] += ga * 2.f * w - gb * 4.f * y; gn[3] += ga * 2.f * x - gb * 4.f * z;
-  }
-  {  // pitch = asin(clamp(s))
-    const float s = 2.f * (w * z - x * y);
-    if (s >= -1.f && s <= 1.f) {
-      const float gs = ge[1] / sqrtf(1.f - s * s);
-      gn[0] += gs * 2.f * z; gn[1] -= gs * 2.f * y; gn[2] -= gs * 2.f * x; gn[3] += gs * 2.f * w;
-    }
-  }
-  {  // yaw = atan2(c, d)
-    const float c = 2.f * (w * x + y * z), d = 1.f - 2.f * (x * x + z * z);
-    const float den = c * c + d * d;
-    const float gc = ge[2] * d / den, gd = -ge[2] * c / den;
-    gn[0] += gc * 2.f * x; gn[1] += gc * 2.f * w - gd * 4.f * x; gn[2] += gc * 2.f * z; gn[3] += gc * 2.f * y - gd * 4.f * z;
-  }
-  const float dot = gn[0] * w + gn[1] * x + gn[2] * y + gn[3] * z;
-  gq[0] = (gn[0] - w * dot) * inv;
-  gq[1] = (gn[1] - x * dot) * inv;
-  gq[2] = (gn[2] - y * dot) * inv;
-  gq[3] = (gn[3] - z * dot) * inv;
-}
-
 // ROWS: `target` holds pre-gathered rows [S*K][25] (kr_gather_targets) instead of the full [S][25][N] states
 template <bool ROWS>
 __global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, int K, const float* __restrict__ base,
@@ -309,9 +271,7 @@ __global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, i
                                                    float* __restrict__ loss, float* __restrict__ dout, int ld_dout) {
   const int64_t rows = S * K;
   float part = 0.f;
-  // weights of the four nn.MSELoss(mean) terms: each is a mean over (rows of the block) x K
-  const float w_p = inv_denom / (3.f * K), w_r = inv_denom / (12.f * K), w_e = inv_denom / (3.f * K),
-              w_z = inv_denom / (6.f * K);
+  const LossWeights lw = loss_weights(inv_denom, K);
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
        row += (int64_t)gridDim.x * blockDim.x) {
     const int64_t s = row / K;
@@ -337,43 +297,7 @@ __global__ __launch_bounds__(256) void loss_kernel(int N, float ds, int64_t S, i
 #pragma unroll
       for (int r = 0; r < 25; ++r) pred[row * 25 + r] = p[r];
     }
-    // positions, physics_train.py:252-253
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float d = p[r] - tgv[r];
-      part += w_p * d * d;
-      g[r] = 2.f * w_p * d;
-    }
-    // n m q w, :254-255
-#pragma unroll
-    for (int r = 7; r < 19; ++r) {
-      const float d = p[r] - tgv[r];
-      part += w_r * d * d;
-      g[r] = 2.f * w_r * d;
-    }
-    // Euler angles of the quaternion, :256-257
-    {
-      float qp[4] = {p[3], p[4], p[5], p[6]};
-      float qt[4] = {tgv[3], tgv[4], tgv[5], tgv[6]};
-      float ep[3], et[3], ge[3], gq[4];
-      q2e(qp, ep);
-      q2e(qt, et);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float d = ep[c] - et[c];
-        part += w_e * d * d;
-        ge[c] = 2.f * w_e * d;
-      }
-      q2e_vjp(qp, ge, gq);
-      g[3] = gq[0]; g[4] = gq[1]; g[5] = gq[2]; g[6] = gq[3];
-    }
-    // z rows against the column before the key point, :258-259
-#pragma unroll
-    for (int r = 19; r < 25; ++r) {
-      const float d = p[r] - tgv[r];
-      part += w_z * d * d;
-      g[r] = 2.f * w_z * d;
-    }
+    part += loss_row(p, tgv, lw, g);
     // chain through pred = base + [ds*out[:19], out[19:]]
 #pragma unroll
     for (int r = 0; r < 19; ++r) dout[row * ld_dout + r] = ds * g[r];
@@ -666,6 +590,35 @@ int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, cons
   return KR_OK;
 }
 
+
+int kr_mlp_forward_loss(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* dims, const int32_t* acts,
+                        const float* const* W, const float* const* b, const float* x, int in_pad, const float* base,
+                        const float* target_rows, double denom, float* out, float* loss, float* dout, void* ws,
+                        void* stream) {
+  KR_CHECK_H(h);
+  if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
+  const int64_t Q = S * K;
+  int rc = check_mlp_shape(n_layers, dims);
+  if (rc) return rc;
+  KR_CHECK_PTR(loss);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (Q > 0 && h->fused_mlp && dims[n_layers] == 25 && acts && fused_mlp_supported(n_layers, dims, acts, in_pad)) {
+    KR_CHECK_PTR(W); KR_CHECK_PTR(b); KR_CHECK_PTR(x); KR_CHECK_PTR(base); KR_CHECK_PTR(target_rows); KR_CHECK_PTR(dout);
+    KR_CHECK_PTR(ws);
+    if (!(denom > 0)) { set_error("denom must be positive"); return KR_E_ARG; }
+    if (Q > (int64_t)1 << 30) { set_error("Q too large"); return KR_E_ARG; }
+    if (!h->grad_accumulate) KR_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    if (!h->loss_scratch) {
+      KR_HIP(hipMalloc(&h->loss_scratch, 4096 * sizeof(float)));  // one partial per workgroup of the forward kernel
+    }
+    FusedLoss fl{base, target_rows, dout, loss, h->loss_scratch, (float)h->derived.ds, (float)(1.0 / denom), K};
+    return fused_mlp_forward(Q, n_layers, dims, acts, W, b, x, out, ws, s, &fl);
+  }
+  KR_CHECK_PTR(out);
+  rc = kr_mlp_forward(h, Q, n_layers, dims, acts, W, b, x, in_pad, out, ws, stream);
+  if (rc) return rc;
+  return kr_loss_rows_fwd_bwd(h, S, K, base, out, target_rows, denom, nullptr, loss, dout, stream);
+}
 
 int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                  const float* lower, double lr, double beta1, double beta2, double eps, double weight_decay,

@@ -81,6 +81,8 @@ _PROTOS = {
     "kr_next_segment_physics": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "kr_mlp_ws_bytes": (C.c_size_t, [_int, C.POINTER(C.c_int32), _i64]),
     "kr_mlp_forward": (_int, [_vp, _i64, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), C.POINTER(_vp), _vp, _int, _vp, _vp, _vp]),
+    "kr_mlp_forward_loss": (_int, [_vp, _i64, _int, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), C.POINTER(_vp),
+                                   _vp, _int, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "kr_mlp_backward": (_int, [_vp, _i64, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), _vp, _int, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "kr_loss_fwd_bwd": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "kr_gather_targets": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp]),

@@ -72,10 +72,12 @@ class KnodeTrainer:
     """
 
     def __init__(self, robot, trajs, controls, key_pt_idx, lr=1e-2, weight_decay=0.0, clamp_weights=True,
-                 patience=80, factor=0.5, group=None, keep_pred=True, native_adam=True):
+                 patience=80, factor=0.5, group=None, keep_pred=False, native_adam=True):
         self.robot = robot
         self.native_adam = native_adam  # Adam + clamp + gradient zeroing as ONE kernel (kr_adam_step)
-        self.keep_pred = keep_pred  # write the predictions of every epoch (needed only by predictions())
+        # keep_pred: write the predictions of every epoch (two kernels: forward, loss); otherwise the loss runs in the
+        # epilogue of the forward kernel and predictions() evaluates them on demand
+        self.keep_pred = keep_pred
         self.group = group
         self.clamp_weights = clamp_weights
         h = robot._native()
@@ -177,12 +179,17 @@ class KnodeTrainer:
         h, s = self.h, kn._stream()
         Wp, bp, dWp, dbp = self._ptr_arrays()
         Q = self.Q
-        kn.check(h.lib.kr_mlp_forward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, bp, kn._ptr(self.x), self.in_pad,
-                                      kn._ptr(self.out), kn._ptr(self.ws), s))
-        kn.check(h.lib.kr_loss_rows_fwd_bwd(h._h, self.S, self.K, kn._ptr(self.base), kn._ptr(self.out),
-                                            kn._ptr(self.target_rows), float(self.steps),
-                                            kn._ptr(self.pred) if self.keep_pred else None,
-                                            kn._ptr(self.bucket.loss), kn._ptr(self.dout), s))
+        if self.keep_pred:
+            kn.check(h.lib.kr_mlp_forward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, bp, kn._ptr(self.x), self.in_pad,
+                                          kn._ptr(self.out), kn._ptr(self.ws), s))
+            kn.check(h.lib.kr_loss_rows_fwd_bwd(h._h, self.S, self.K, kn._ptr(self.base), kn._ptr(self.out),
+                                                kn._ptr(self.target_rows), float(self.steps), kn._ptr(self.pred),
+                                                kn._ptr(self.bucket.loss), kn._ptr(self.dout), s))
+        else:  # the loss runs in the epilogue of the forward kernel where the fused kernels serve the network
+            kn.check(h.lib.kr_mlp_forward_loss(h._h, self.S, self.K, self.n, self.dims_c, self.acts_c, Wp, bp,
+                                               kn._ptr(self.x), self.in_pad, kn._ptr(self.base), kn._ptr(self.target_rows),
+                                               float(self.steps), kn._ptr(self.out), kn._ptr(self.bucket.loss),
+                                               kn._ptr(self.dout), kn._ptr(self.ws), s))
         kn.check(h.lib.kr_mlp_backward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, kn._ptr(self.x), self.in_pad,
                                        kn._ptr(self.dout), kn._ptr(self.ws), dWp, dbp, s))
         self.bucket.all_reduce(self.group)
@@ -268,5 +275,14 @@ class KnodeTrainer:
         self.adam_step = steps.pop()
 
     def predictions(self):
-        """[S, 25, K] predictions of the last forward pass (reference layout of grow_trajs)."""
+        """[S, 25, K] predictions with the current weights (reference layout of grow_trajs)."""
+        if not self.keep_pred:
+            h = self.h
+            Wp, bp, _, _ = self._ptr_arrays()
+            kn.check(h.lib.kr_mlp_forward(h._h, self.Q, self.n, self.dims_c, self.acts_c, Wp, bp, kn._ptr(self.x),
+                                          self.in_pad, kn._ptr(self.out), kn._ptr(self.ws), kn._stream()))
+            ds = float(h.derived().ds)
+            self.pred[: self.Q] = self.base[: self.Q]
+            self.pred[: self.Q, :19] += ds * self.out[: self.Q, :19]   # cosserat_ode_torch.py:386-393: y + ds ys, z as is
+            self.pred[: self.Q, 19:] += self.out[: self.Q, 19:25]
         return self.pred[: self.Q].reshape(self.S, self.K, 25).transpose(1, 2)

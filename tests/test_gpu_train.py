@@ -116,16 +116,18 @@ def test_slow_path_reference_loop(torch_cuda):
     _check_grads_and_post(torch, rob, g, "slow")
 
 
+@pytest.mark.parametrize("keep_pred", [False, True])
 @pytest.mark.parametrize("path,kp", [("fast", [3, 5, 7, 9]), ("slow", [2, 6, 9])])
-def test_fused_trainer(torch_cuda, path, kp):
-    """KnodeTrainer: fused prediction + loss + backward + Adam + clamp equals the reference epoch."""
+def test_fused_trainer(torch_cuda, path, kp, keep_pred):
+    """KnodeTrainer: fused prediction + loss + backward + Adam + clamp equals the reference epoch - with the loss in
+    the epilogue of the forward kernel (kr_mlp_forward_loss, the default) and as a kernel of its own (keep_pred)."""
     torch = torch_cuda
     from krod_train import KnodeTrainer
     g = load_golden("train_step")
     rob = make_robot(torch, g)
     traj = torch.tensor(g["traj"], device=DEV)[None]
     controls = torch.tensor(g["controls"], device=DEV)[None]
-    tr = KnodeTrainer(rob, traj, controls, kp)
+    tr = KnodeTrainer(rob, traj, controls, kp, keep_pred=keep_pred)
     loss = tr.loss_and_grads()
     torch.cuda.synchronize()
     assert abs(float(loss.item()) - float(g[f"{path}_loss"])) < 2e-5 * abs(float(g[f"{path}_loss"]))
@@ -230,6 +232,76 @@ def test_mlp_forward_backward_vs_torch(torch_cuda, sizes, acts, Q):
     for a, p in zip(got, ref_mods.parameters()):
         assert rel_l2(a.cpu().numpy(), p.grad.cpu().numpy()) < 2e-5
     ref_mods.float()
+
+
+@pytest.mark.parametrize("dims,acts,S,K", [([28, 64, 64, 25], [4, 4, 0], 37, 4), ([28, 512, 25], [4, 0], 41, 3),
+                                           ([28, 64, 25], [1, 0], 1, 1), ([28, 40, 40, 25], [2, 2, 0], 300, 4),
+                                           ([28, 96, 96, 25], [4, 4, 0], 10, 2)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_forward_loss_fused_equals_two_kernels(torch_cuda, dims, acts, S, K, accumulate):
+    """kr_mlp_forward_loss (loss in the epilogue of the fused forward kernel; the last shape is one the fused kernels
+    do not serve: generic path) against kr_mlp_forward + kr_loss_rows_fwd_bwd on the same rows: loss and d loss / d out,
+    row counts that are not multiples of the 32-row blocks, option mlp_grad_accumulate on and off."""
+    torch = torch_cuda
+    import ctypes as C
+    import krod_native as kn
+    from cosserat_ode import CosseratRod
+    rng = np.random.default_rng(17)
+    r = CosseratRod()
+    r.N = 10
+    r.compute_intermediate_terms()
+    h = r._native()
+    Q, n = S * K, len(acts)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    Ws = [t(0.3 * rng.standard_normal((dims[k + 1], dims[k])) / np.sqrt(dims[k])) for k in range(n)]
+    bs = [t(0.1 * rng.standard_normal(dims[k + 1])) for k in range(n)]
+    x = torch.zeros((Q, 32), dtype=torch.float32, device=DEV)
+    x[:, :28] = t(rng.standard_normal((Q, 28)))
+    base = t(rng.standard_normal((Q, 25)))
+    base[:, 3] += 2.0
+    tgt = t(rng.standard_normal((Q, 25)))
+    tgt[:, 3] += 2.0
+    dims_c = (C.c_int32 * (n + 1))(*dims)
+    acts_c = (C.c_int32 * n)(*acts)
+    Wp = (C.c_void_p * n)(*[w.data_ptr() for w in Ws])
+    bp = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+    ws = torch.empty(max(h.lib.kr_mlp_ws_bytes(n, dims_c, Q), 16), dtype=torch.uint8, device=DEV)
+    h.set_option("mlp_grad_accumulate", accumulate)
+    try:
+        out1 = torch.zeros((Q, 32), dtype=torch.float32, device=DEV)
+        dout1 = torch.full((Q, 32), 7.0, dtype=torch.float32, device=DEV)
+        loss1 = torch.full((1,), 0.5, dtype=torch.float32, device=DEV)
+        kn.check(h.lib.kr_mlp_forward(h._h, Q, n, dims_c, acts_c, Wp, bp, kn._ptr(x), 32, kn._ptr(out1), kn._ptr(ws), kn._stream()))
+        kn.check(h.lib.kr_loss_rows_fwd_bwd(h._h, S, K, kn._ptr(base), kn._ptr(out1), kn._ptr(tgt), 29.0, None,
+                                            kn._ptr(loss1), kn._ptr(dout1), kn._stream()))
+        out2 = torch.zeros((Q, 32), dtype=torch.float32, device=DEV)
+        dout2 = torch.full((Q, 32), 7.0, dtype=torch.float32, device=DEV)
+        loss2 = torch.full((1,), 0.5, dtype=torch.float32, device=DEV)
+        kn.check(h.lib.kr_mlp_forward_loss(h._h, S, K, n, dims_c, acts_c, Wp, bp, kn._ptr(x), 32, kn._ptr(base), kn._ptr(tgt),
+                                           29.0, kn._ptr(out2), kn._ptr(loss2), kn._ptr(dout2), kn._ptr(ws), kn._stream()))
+        torch.cuda.synchronize()
+    finally:
+        h.set_option("mlp_grad_accumulate", 0)
+    l1, l2 = float(loss1), float(loss2)
+    assert (l1 > 0.5) == bool(accumulate) or l1 > 0  # accumulate: added to the 0.5 that was there
+    assert abs(l1 - l2) < 2e-6 * abs(l1)
+    assert float((dout1 - dout2).abs().max()) < 1e-5 * float(dout1.abs().max())  # (fp32: the two kernels contract differently)
+    assert float(dout2[:, 25:].abs().max()) == 0.0
+    # the backward pass that follows finds the activations the fused forward left in the workspace
+    dW1 = [torch.zeros_like(w) for w in Ws]; db1 = [torch.zeros_like(b) for b in bs]
+    dWp = (C.c_void_p * n)(*[w.data_ptr() for w in dW1]); dbp = (C.c_void_p * n)(*[b.data_ptr() for b in db1])
+    kn.check(h.lib.kr_mlp_backward(h._h, Q, n, dims_c, acts_c, Wp, kn._ptr(x), 32, kn._ptr(dout2), kn._ptr(ws), dWp, dbp, kn._stream()))
+    xs = x[:, :28].double().requires_grad_(False)
+    a = xs
+    Wd = [w.double().requires_grad_(True) for w in Ws]
+    bd = [b.double().requires_grad_(True) for b in bs]
+    actf = {0: lambda v: v, 1: torch.tanh, 2: torch.nn.functional.softplus, 3: torch.relu, 4: torch.nn.functional.elu}
+    for k in range(n):
+        a = actf[acts[k]](a @ Wd[k].t() + bd[k])
+    (a * dout2[:, :25].double()).sum().backward()
+    for k in range(n):
+        assert rel_l2(dW1[k].cpu().numpy(), Wd[k].grad.cpu().numpy()) < 2e-5
+        assert rel_l2(db1[k].cpu().numpy(), bd[k].grad.cpu().numpy()) < 2e-5
 
 
 def test_loss_kernel_vs_torch_autograd(torch_cuda):
