@@ -31,6 +31,12 @@ done
 echo "[7] batched ODE kernel"
 timeout -k 10 200 python3 tools/aux_bench.py ode > $out/${tag}_ode.txt 2>&1; grep ode_batch $out/${tag}_ode.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_ode_stats -- python3 tools/aux_bench.py ode > /dev/null 2>&1 || true
+echo "[9] cfg5 (N = 400, B = 512): the several-wavefront step kernel"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_cfg5_stats -- python3 tools/cfg5_only.py > $out/${tag}_cfg5.log 2>&1 || true
+grep cfg5 $out/${tag}_cfg5.log
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_cfg5_fetch -- python3 tools/cfg5_only.py > /dev/null 2>&1 || true
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_cfg5_write -- python3 tools/cfg5_only.py > /dev/null 2>&1 || true
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $out/${tag}_cfg5_sq -- python3 tools/cfg5_only.py > /dev/null 2>&1 || true
 echo "[8] all five BASELINE configurations"
 timeout -k 10 600 python3 tools/config_report.py > $out/${tag}_configs.txt 2>&1; grep -v amdgpu $out/${tag}_configs.txt
 echo collected

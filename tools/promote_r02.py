@@ -62,6 +62,31 @@ if st: rec["kernel_stats"] = stats_rows(st, ("ode_batch",))
 t = os.path.join(G, f"{tag}_ode.txt")
 if os.path.exists(t): rec["lines"] = [l.strip() for l in open(t) if l.startswith("ode_batch")]
 out["ode_batch"] = rec
+# cfg5 on the several-wavefront step kernel: kernel stats, HBM bytes per launch (FETCH_SIZE / WRITE_SIZE: units of 32 B on
+# gfx950 as in tools/summarise_profiles.py) against the algorithmic (75 N + 16) s B, SQ issue figures
+st = newest(os.path.join(G, f"{tag}_cfg5_stats", "**", "*kernel_stats.csv"))
+rec = {"what": "tools/cfg5_only.py: B=512, N=400, fp64, 30 + 60 steps, one launch per step, two wavefronts per rod"}
+if st: rec["kernel_stats"] = stats_rows(st, ("msw_step_kernel", "ms_step_kernel"))
+log = os.path.join(G, f"{tag}_cfg5.log")
+if os.path.exists(log): rec["line"] = [l.strip() for l in open(log) if l.startswith("cfg5")][-1:]
+for cname, d in (("FETCH_SIZE", f"{tag}_cfg5_fetch"), ("WRITE_SIZE", f"{tag}_cfg5_write")):
+    c = counters(d, "msw_step_kernel")
+    if c:
+        rec.setdefault("hbm", {})[cname + "_raw_per_launch"] = c["sum_over_dispatches"].get(cname, 0.0) / max(c["dispatches"], 1)
+if "hbm" in rec:
+    # counters are in KB; FETCH_SIZE on gfx950 counts half the bytes of 16-B-per-lane reads -> doubled (as in
+    # tools/summarise_profiles.py, MI355X_MICROARCH.md HBM section); WRITE_SIZE exact for 16-B-per-lane stores
+    f_, w_ = rec["hbm"].get("FETCH_SIZE_raw_per_launch", 0.0), rec["hbm"].get("WRITE_SIZE_raw_per_launch", 0.0)
+    rec["hbm"]["hbm_bytes_per_launch_corrected"] = int(2 * f_ * 1024 + w_ * 1024)
+    rec["hbm"]["algorithmic_bytes_per_launch"] = (75 * 400 + 16) * 8 * 512
+c = counters(f"{tag}_cfg5_sq", "msw_step_kernel")
+if c:
+    c["waves_per_simd"] = 1
+    a = c["sum_over_dispatches"]
+    if a.get("SQ_BUSY_CYCLES") and a.get("SQ_INSTS_VALU"):
+        c["note"] = "valu issue fraction = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x launch cycles): see bench roofline for the formula"
+    rec["sq"] = c
+out["cfg5_msw"] = rec
 json.dump(out, open(os.path.join(P, f"{tag}_kernels.json"), "w"), indent=1)
 for name in ("configs.txt", "train.txt"):
     src = os.path.join(G, f"{tag}_{name}")
