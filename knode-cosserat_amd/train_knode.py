@@ -6,8 +6,8 @@ evaluation :136-167, checkpoint :284-288), running on the MI355X kernels:
   * reference trajectories: ``knode.simulate(robot_reference, controls)`` (persistent multiple-shooting kernel),
   * epoch: ``krod_train.KnodeTrainer.step`` - fused MLP forward / loss / backward / Adam + clamp, every
     (trajectory, window step, key point) row in one batch,
-  * evaluation every 50 epochs: closed-loop rollout with the live weights (``krod_eval.evaluate``), exact DTW of the
-    tip path against the validation reference (the reference uses ``fastdtw``, an approximation of it),
+  * evaluation every 50 epochs: closed-loop rollout with the live weights (``krod_eval.evaluate``), FastDTW of the
+    tip path against the validation reference (radius 1, L1: what the reference's ``fastdtw`` call computes, restated),
   * checkpoint: ``torch.save({'robot', 'dtw', 'loss', 'optim'})`` - readable by the reference; ``optim`` is an
     Adam ``state_dict`` (step, exp_avg, exp_avg_sq per parameter + param_groups), ``--resume`` continues from it.
 

@@ -313,6 +313,25 @@ def test_dtw_and_eval_metrics(tmp_path):
     x = rng.standard_normal(30)
     assert ke.dtw_distance(x, x) == 0.0
     assert ke.dtw_distance(np.repeat(x, 2), x) == 0.0  # warping absorbs a uniform slow-down
+    # FastDTW (restated from Salvador & Chan 2007; what the reference's evaluate calls with radius 1): never below the
+    # exact DTW, equal to it once the radius covers the table, on short series (below radius + 2 samples the algorithm IS
+    # the exact one) and on the kind of data it is used on (two close, smooth tip paths); hand-checked small case
+    for (ta, tb, d) in ((1, 1, 3), (2, 5, 3), (40, 33, 3), (64, 64, 1), (101, 57, 3)):
+        a, b = rng.standard_normal((ta, d)), rng.standard_normal((tb, d))
+        ex = ke.dtw_distance(a, b)
+        f1 = ke.fastdtw_distance(a, b)
+        assert f1 >= ex - 1e-12
+        assert abs(ke.fastdtw_distance(a, b, radius=max(ta, tb)) - ex) < 1e-10 * max(1.0, ex)
+        if min(ta, tb) < 3:
+            assert abs(f1 - ex) < 1e-12
+    t = np.linspace(0, 4, 200)
+    path = np.stack([0.1 * np.sin(3 * t), 0.1 * np.cos(2 * t), 0.4 + 0.01 * t], axis=1)
+    other = path + 1e-3 * np.stack([np.sin(5 * t), np.cos(7 * t), np.sin(t)], axis=1)
+    assert abs(ke.fastdtw_distance(path, other) - ke.dtw_distance(path, other)) < 0.05 * ke.dtw_distance(path, other)
+    assert ke.fastdtw_distance(x, x) == 0.0
+    # x = [0 1 2 3], y = [0 0 1 2 3]: halves (0.5, 2.5) / (0, 1.5), coarse path (0,0) (1,1); refined window holds the
+    # optimal alignment of cost 0
+    assert ke.fastdtw_distance(np.array([0.0, 1, 2, 3]), np.array([0.0, 0, 1, 2, 3])) == 0.0
     # pos + euler MSE
     T, N = 6, 5
     tr = rng.standard_normal((T, 25, N)); rf = tr + 0.01 * rng.standard_normal((T, 25, N))
