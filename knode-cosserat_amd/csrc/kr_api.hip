@@ -170,7 +170,7 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
                          const void* prev_init, hipStream_t s) {
   const size_t slot = (size_t)B * h->params.N * KR_SLOTS;
   T* base = (T*)states;
-  {
+  if (step_waves_per_rod<T>(h, scheme, use_nn, B, 0) < 2) {  // (else: several wavefronts per rod, one launch per step)
     // one launch for all steps when the multiple-shooting kernel applies
     auto a0 = make_args<T>(h, B, nullptr, nullptr, nullptr, G, ctl, 4, tol, maxit);
     SimArgs<T> sa{};

@@ -154,6 +154,44 @@ __device__ __forceinline__ double msw_sum(double v, double* red, int wave, int l
   return s;
 }
 
+// two maxima at once (one pair of barriers)
+template <int W>
+__device__ __forceinline__ void msw_max2(float& a, float& b, float* red, int wave, int lane) {
+  a = wave_max_nonneg(a);
+  b = wave_max_nonneg(b);
+  if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+  __syncthreads();
+  a = red[0]; b = red[1];
+#pragma unroll
+  for (int k = 1; k < W; ++k) { a = fmaxf(a, red[2 * k]); b = fmaxf(b, red[2 * k + 1]); }
+  __syncthreads();
+}
+
+// Scaled maximum norm of this wavefront's part of the residual of a sweep (see ms_residual_norm): the interface
+// jumps E_g - Y_{g+1} of its intervals (19 rows each) and, on the last wavefront, the tip condition - from the end
+// states of the unperturbed lanes in Es.  Not yet reduced over the workgroup.
+template <typename T, int W>
+__device__ __forceinline__ float msw_residual_local(const T* Es, const T* Xs, const T* cold, const MswRole& R, int lane) {
+  constexpr int P = MswGeo<W>::P;
+  float rn = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = lane + 64 * q;
+    const int k = e / 19, r = e - 19 * k;
+    const int g = R.g0 + k;
+    if (k < R.K && g < P - 1) {
+      const T x = Xs[(g + 1) * 19 + r];
+      rn = fmaxf(rn, update_ratio(Es[msw_l0(R.w, k) * 19 + r] - x, x));
+    }
+  }
+  if (R.w == W - 1 && lane >= 58) {  // (lanes the loop above never uses on the last wavefront: 2 x 19 = 38 entries)
+    const int k = lane - 58;
+    const T e = Es[msw_l0(R.w, 2) * 19 + 7 + k];
+    rn = fmaxf(rn, update_ratio(cold[CD_FTIP + k] - e, e));
+  }
+  return rn;
+}
+
 // ---- predictor of one wavefront's unknowns (NE = K x 19 entries of Xs starting at interval g0) -------------------
 template <typename T>
 __device__ __forceinline__ void mswp_init(MsPred<T>& Q, int lane, int ne, int g0, int N, int P, const T* s0, const T* sp,
@@ -326,6 +364,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
   T dn_prev = T(-1);
   const T kappa_in = S.kappa;
   bool below = false;
+  float amp = -1.f;  // |update| / |residual| of the last full iteration of this solve (residual test, see ms_newton)
 
   while (true) {
     // ---- start state of this lane, forward-difference step of its column -------------------------------
@@ -377,6 +416,33 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
     unsigned long long ta = tq;
 #endif
 
+    // ---- residual test of a storing sweep that follows a small update (kr_ms_impl.hpp, ms_newton) ------------
+    float res_local = 0.f;
+    if (storing && amp > 0.f && dn_prev > T(0) && dn_prev <= T(1e-2)) {
+      {
+        T er[19];
+        state_to_rows(y, er);
+        if (col == 0 && !idle) {
+#pragma unroll
+          for (int q = 0; q < 19; ++q) Es[lane * 19 + q] = er[q];
+        }
+      }
+      wave_sync();
+      const float rn = msw_max<W>(msw_residual_local<T, W>(Es, Xs, L.cold, R, lane), redf, wave, lane);
+      const float est = amp * rn;
+#ifdef KR_QUICK_AUDIT
+      stamps.qn = (double)est;  // compared with the update below
+#else
+      if (T(256) * (T)est <= S.tol) {  // (NaN compares false)
+        status = KR_ST_CONVERGED;
+        if (!below && dn_prev > T(0)) {
+          const T floor_dn = T(64) * (sizeof(T) == 8 ? T(2.2e-16) : T(1.2e-7));
+          S.kappa = fmin(fmax(fmax((T)est, floor_dn) * fast_rcp(dn_prev * dn_prev), T(1e-4)), T(1));
+        }
+        break;
+      }
+#endif
+    }
     // ---- end states and forward-difference columns of this wavefront's intervals -------------------------
     {
       T er[19];
@@ -386,6 +452,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
         for (int q = 0; q < 19; ++q) Es[lane * 19 + q] = er[q];
       }
       wave_sync();
+      res_local = msw_residual_local<T, W>(Es, Xs, L.cold, R, lane);
       if (col > 0) {
         const T ih = fast_rcp(hstep);
         T e0[19];
@@ -668,9 +735,13 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       updG = L.dY[0 * 19 + 7 + k];
       dnf = fmaxf(dnf, update_ratio(updG, xsG));
     }
-    dnf = msw_max<W>(dnf, redf, wave, lane);
+    msw_max2<W>(dnf, res_local, redf, wave, lane);
     const bool finite = dnf <= 3.0e38f;
     const T dn = (T)dnf;
+    if (finite && res_local > 0.f) amp = dnf / res_local;
+#if defined(KR_MS_STAMPS) && defined(KR_QUICK_AUDIT)
+    if (stamps.qn > 0.0 && finite && dnf > 0.f) { stamps.qa = fmax(stamps.qa, (double)dnf / stamps.qn); stamps.qn = 0.0; }
+#endif
     if (finite && !below && dn <= S.tol) {
       below = true;
       if (dn_prev > T(0)) {
@@ -823,7 +894,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
     if (A.iters) A.iters[rod * A.st_stride] = it;
   }
 #ifdef KR_MS_STAMPS
-  // diagnostic build (tools/msw_stamps.py): the debug buffer is [15][B][T] int32, plane k = quantity k of wavefront W-1
+  // diagnostic build (tools/msw_stamps.py): the debug buffer is [16][B][T] int32, plane k = quantity k of wavefront W-1
   if (wave == W - 1 && lane == 0 && A.iters) {
     unsigned long long t_end;
     KR_STAMP(t_end);
@@ -840,6 +911,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
     o[9 * plane] = (int32_t)stamps.a4;
     for (int k = 0; k < 4; ++k) o[(10 + k) * plane] = __float_as_int((float)stamps.dn[k]);
     o[14 * plane] = __float_as_int((float)S.kappa);
+    o[15 * plane] = __float_as_int((float)stamps.qa);  // KR_QUICK_AUDIT: (update) / (residual estimate) of this step
   }
 #endif
 }
@@ -847,8 +919,8 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
 template <typename T, int W>
 static size_t msw_lds_bytes(int N) { return sizeof(T) * msw_lds_elems<T, W>(N); }
 
-// wavefronts per rod this call should use (0: not this kernel).  Auto: long rods (no persistent form) in batches
-// that leave SIMDs idle; the option "waves_per_rod" forces 1 / 2 / 4.
+// wavefronts per rod this call should use (0: not this kernel).  Auto: batches that leave SIMDs idle - long rods (no
+// persistent form) and rods of 80 grid points and more; the option "waves_per_rod" forces 1 / 2 / 4.
 template <typename T>
 int step_waves_per_rod(kr_handle* h, int scheme, int use_nn, int64_t B, int mode) {
   const RodConst<T>& P = consts<T>(h);
@@ -863,7 +935,14 @@ int step_waves_per_rod(kr_handle* h, int scheme, int use_nn, int64_t B, int mode
   if (h->waves_per_rod == 1) return 0;
   if (h->waves_per_rod == 2) return fits(2, b2) ? 2 : 0;
   if (h->waves_per_rod == 4) return fits(4, b4) ? 4 : 0;
-  if (P.N <= MS_NPL * WAVE) return 0;  // the persistent one-wavefront kernel serves these
+  if (P.N <= MS_NPL * WAVE) {
+    // the persistent one-wavefront kernel serves these; four wavefronts per rod, one launch per step, are faster
+    // only when three quarters of the chip would idle otherwise and the rod is long enough for the shorter chains to
+    // pay for the distributed condensation (tools/msw_timing.py, B = 256: N = 100 30.3 against 35.8 us per step,
+    // N = 40 25.5 against 20.3)
+    if (P.N >= 80 && B * 4 <= 1024 && fits(4, b4)) return 4;
+    return 0;
+  }
   if (B * 4 <= 1024 && fits(4, b4)) return 4;
   if (B * 2 <= 1024 && fits(2, b2)) return 2;
   return 0;

@@ -210,22 +210,28 @@ def test_iteration_cap_is_reported(torch_cuda, waves):
 
 def test_auto_choice(torch_cuda, monkeypatch):
     """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512, one beyond;
-    N = 100 (served by the persistent kernel) never takes this path."""
+    N = 100 takes four up to B = 256 and the persistent one-wavefront kernel beyond; N = 40 always the persistent one."""
     torch = torch_cuda
     set_mode_env(monkeypatch, "persistent", waves_per_rod=0)
-    r = make_robot(None, 400)
-    h = r._native()
-    for B, want in ((1, 4), (256, 4), (257, 2), (512, 2), (513, 1)):
+
+    def run(h, B):
         st = h.new_state(B, torch.float64, n_slots=3)
         h.init_straight(st[0])
         G = torch.zeros((B, 6), dtype=torch.float64, device=DEV)
         ctl = torch.zeros((B, 2, 4), dtype=torch.float64, device=DEV)
         ctl[:, :, 0] = 1.0
-        h.simulate(ctl, st, G)
+        status = torch.full((B, 2), -1, dtype=torch.int32, device=DEV)
+        h.simulate(ctl, st, G, status=status)
+        assert int((status != 0).sum()) == 0
+
+    h = make_robot(None, 400)._native()
+    for B, want in ((1, 4), (256, 4), (257, 2), (512, 2), (513, 1)):
+        run(h, B)
         assert_path(h, 1, want)
-    r2 = make_robot(None, 100)
-    h2 = r2._native()
-    st = h2.new_state(4, torch.float64, n_slots=3)
-    h2.init_straight(st[0])
-    h2.simulate(torch.zeros((4, 2, 4), dtype=torch.float64, device=DEV), st, torch.zeros((4, 6), dtype=torch.float64, device=DEV))
-    assert_path(h2, 2)
+    h = make_robot(None, 100)._native()
+    for B, path, want in ((4, 1, 4), (256, 1, 4), (257, 2, 1)):
+        run(h, B)
+        assert_path(h, path, want)
+    h = make_robot(None, 40)._native()
+    run(h, 4)
+    assert_path(h, 2)

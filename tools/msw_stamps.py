@@ -14,7 +14,7 @@ T, warm = 40, 40
 dev = "cuda:0"; dt = torch.float64
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
 h = r._native(); h.set_option("persistent", 0); h.set_option("keep_predictor", 1); h.set_option("waves_per_rod", W)
-dbg = torch.zeros((15, B, T), dtype=torch.int32, device=dev)
+dbg = torch.zeros((16, B, T), dtype=torch.int32, device=dev)
 ctl = torch.as_tensor(orc.batch_sine_controls(B, warm + T, r.del_t, 77), device=dev).contiguous()
 st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
 h.simulate(ctl[:, :warm].contiguous(), st, G, ring=True)
@@ -24,6 +24,7 @@ h.simulate(ctl[:, warm:].contiguous(), st, G, ring=True, prev_init=st[2])
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = dbg.cpu().numpy().astype(np.float64)
 dnv = dbg[10:15].cpu().numpy().view(np.float32)
+qa = dbg[15].cpu().numpy().view(np.float32)
 names = ["sweeps", "total", "prologue", "sweep", "algebra", "pred update+save", "alg: hand-over+local chain", "alg: barrier wait",
          "alg: combine", "alg: solve+update+norm"]
 print(f"N={N} B={B} W={W} (ran {h.get_option('last_waves_per_rod')}): wall {el/T*1e6:.1f} us/step (with the debug stores)")
@@ -36,3 +37,5 @@ for k in (2, 3, 4):
     m = ii == k
     if m.any():
         print(f"  rod-steps with {k} sweeps: median update norms " + " ".join(f"{np.median(dnv[q][m]):.2e}" for q in range(4)) + f"  kappa {np.median(dnv[4][m]):.2e}")
+if qa.max() > 0:
+    print(f"  residual-test audit (-DKR_QUICK_AUDIT): (update) / (estimate) worst {qa.max():.1f}, median of the audited steps {np.median(qa[qa > 0]):.1f}, audited {int((qa > 0).sum())} of {qa.size}")
