@@ -21,13 +21,16 @@ if NN:
         if a_ != orc.ACT_NONE: model.append("ELU(alpha=1.0)")
     r.nn_model, r.param_ls, r.nn_path = model, params, "x"
 h = r._native(); h.set_option("ms_mode", 1); h.set_option("persistent", 1)
+WARM = int(os.environ.get("KR_STAMP_WARM", "21"))
+if os.environ.get("KR_STAMP_KEEP"): h.set_option("keep_predictor", 1)   # steady state: the timed call resumes the predictor
 dbg = torch.zeros((B, 24), dtype=torch.int64, device=dev)
 kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
-ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 1235), device=dev).contiguous()
+ctl_all = torch.as_tensor(orc.batch_sine_controls(B, WARM + T, r.del_t, 1235), device=dev).contiguous()
+ctl = ctl_all[:, WARM:].contiguous() if os.environ.get("KR_STAMP_KEEP") else ctl_all[:, :T].contiguous()
 for pred in (7, 8):
     h.set_option("predictor", pred)
     st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
-    h.simulate(ctl[:, :21].contiguous(), st, G, ring=True, use_nn=NN)
+    h.simulate(ctl_all[:, :WARM].contiguous(), st, G, ring=True, use_nn=NN)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     h.simulate(ctl, st, G, ring=True, prev_init=st[2], use_nn=NN)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
