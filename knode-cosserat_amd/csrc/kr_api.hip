@@ -170,8 +170,10 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
                          const void* prev_init, hipStream_t s) {
   const size_t slot = (size_t)B * h->params.N * KR_SLOTS;
   T* base = (T*)states;
-  if (step_waves_per_rod<T>(h, scheme, use_nn, B, 0) < 2) {  // (else: several wavefronts per rod, one launch per step)
-    // one launch for all steps when the multiple-shooting kernel applies
+  const int wpr = step_waves_per_rod<T>(h, scheme, use_nn, B, 0);  // (one predictor image per wavefront of a rod)
+  const int img_w = wpr ? wpr : 1;
+  {
+    // one launch for all steps when a multiple-shooting kernel with a persistent form applies
     auto a0 = make_args<T>(h, B, nullptr, nullptr, nullptr, G, ctl, 4, tol, maxit);
     SimArgs<T> sa{};
     sa.B = B; sa.T_steps = T_steps; sa.states = base; sa.slot_elems = (int64_t)slot; sa.ring = ring;
@@ -180,16 +182,16 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
     sa.maxit = a0.maxit; sa.predictor = h->predictor;
     sa.dbg = static_cast<unsigned long long*>(h->dbg);
     sa.pred_io = nullptr; sa.pred_load = 0;
-    if (h->keep_predictor && (size_t)B * KR_PRED_IMG_DOUBLES * sizeof(double) <= ((size_t)1 << 30)) {
-      int rcp = ensure_pred(h, B);
+    if (h->keep_predictor && (size_t)B * img_w * KR_PRED_IMG_DOUBLES * sizeof(double) <= ((size_t)1 << 30)) {
+      int rcp = ensure_pred(h, B * img_w);
       if (rcp) return rcp;
       sa.pred_io = static_cast<double*>(h->pred_buf);
-      sa.pred_load = h->pred_valid_B == B && h->pred_valid_W == 1;
+      sa.pred_load = h->pred_valid_B == B && h->pred_valid_W == img_w;
     }
     const int rc = launch_sim_persistent<T>(h, scheme, use_nn, sa, s);
     if (rc != 1) {
       h->last_sim_path = 2;
-      if (rc == KR_OK && sa.pred_io) { h->pred_valid_B = B; h->pred_valid_W = 1; }
+      if (rc == KR_OK && sa.pred_io) { h->pred_valid_B = B; h->pred_valid_W = img_w; }
       return rc;
     }
   }
@@ -197,8 +199,6 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
   // one launch per step: the multiple-shooting kernel carries its start-value predictor from launch to launch
   // through an image in HBM (12 KB per rod; skipped for batches that would need more than 1 GB of it)
   double* pred = nullptr;
-  const int wpr = step_waves_per_rod<T>(h, scheme, use_nn, B, 0);  // (one image per wavefront of a rod)
-  const int img_w = wpr ? wpr : 1;
   if (h->predictor > 2 && h->ms_mode != 0 && (h->ms_mode == 1 || B <= (int64_t)h->ms_batch_limit)) {
     const size_t need = (size_t)B * img_w * KR_PRED_IMG_DOUBLES * sizeof(double);
     if (need <= ((size_t)1 << 30)) {

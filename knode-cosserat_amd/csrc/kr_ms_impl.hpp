@@ -301,6 +301,9 @@ struct MsSolveArgs {
   // contraction constant |d_{k+1}| / |d_k|^2 seen where an earlier solve of this rod first got below the
   // tolerance (0: unknown).  In: used to decide which sweep streams the state out; out: refreshed.
   T kappa;
+  // persistent several-wavefront kernel (kr_msw_impl.hpp): where a storing sweep also leaves the twelve leading slots
+  // of every record, [N][12] in LDS (nullptr: nowhere)
+  T* lead12 = nullptr;
 };
 
 // Scaled maximum norm of the residual of a sweep - the interface jumps E_g - Y_{g+1} (19 rows each) and the tip
@@ -1575,11 +1578,16 @@ static int launch_ms_sim_inst(const RodConst<T>& P, const MlpDev<T>& M, const Si
   return KR_OK;
 }
 
+template <typename T>
+static int launch_msw_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s);  // kr_msw_impl.hpp
+
 // returns 1 when the persistent form does not apply (caller falls back to one launch per step)
 template <typename T>
 int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>& a, hipStream_t s) {
   const RodConst<T>& P = consts<T>(h);
   if (h->ms_mode == 0 || h->persistent == 0) return 1;
+  if (const int W = step_waves_per_rod<T>(h, scheme, use_nn, a.B, 0)) return launch_msw_sim<T>(h, W, a, s);  // several wavefronts per rod
+  h->last_waves_per_rod = 1;
   const MlpDev<T>& M = mlpdev<T>(h);
   if (use_nn) {
     // MLP inside the sweeps: the matrix-core evaluator, Euler sweeps and diagonal material matrices only (one

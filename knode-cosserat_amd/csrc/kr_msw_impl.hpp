@@ -390,6 +390,12 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
           T rec[KR_SLOTS];
           record_from(y, v, u, rec);
           store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
+          if (S.lead12) {
+            T lead[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+            store_vec<T, 12>(S.lead12 + (size_t)j * 12, lead);
+          }
         }
       }
       load_hist_vec<T, HS_LEAN>(L.hist + (size_t)(j + 1) * HS_LEAN, hv);
@@ -407,6 +413,12 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       T rec[KR_SLOTS];
       record_from(y, S.vlast, S.ulast, rec);
       store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+      if (S.lead12) {
+        T lead[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+        store_vec<T, 12>(S.lead12 + (size_t)(N - 1) * 12, lead);
+      }
       if (S.tip) { S.tip[0] = y.p.x; S.tip[1] = y.p.y; S.tip[2] = y.p.z; }
     }
     if (flush) break;
@@ -916,35 +928,172 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
 #endif
 }
 
+// ---- all steps of kr_simulate_batch in one launch: the same solver, the leading slots of the two newest states kept in
+// LDS (the history records of the next step never touch HBM), the predictors in registers ---------------------------
+template <typename T, int W>
+__host__ __device__ inline size_t msw_sim_lds_elems(int N) { return msw_lds_elems<T, W>(N) + (size_t)2 * N * 12; }
+
+template <typename T, bool DIAG, int W>
+__global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A) {
+  constexpr int P = MswGeo<W>::P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = Pc.N;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int64_t rod = blockIdx.x;
+  const size_t rod_elems = (size_t)N * KR_SLOTS;
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const MswLds<T, W> L = msw_carve<T, W>(smem, N);
+  T* lead0 = smem + msw_lds_elems<T, W>(N);  // [2][N][12]: newest state / the one before (roles alternate)
+  const int lsz = N * 12;
+  const MswRole R = msw_role<W>(wave, lane, N);
+  MsStamps stamps;
+  if (wave == 0) ms_cold_fill<T>(Pc, L.cold, lane);
+  const T* s0 = A.states + rod * rod_elems;
+  const T* sp = A.prev_init ? A.prev_init + rod * rod_elems : s0;
+  for (int j = threadIdx.x; j < N; j += WAVE * W) {
+    T cv[12], pv[12];
+    load_hist_vec<T, 12>(s0 + (size_t)j * KR_SLOTS, cv);
+    load_hist_vec<T, 12>(sp + (size_t)j * KR_SLOTS, pv);
+    store_vec<T, 12>(lead0 + (size_t)j * 12, cv);
+    store_vec<T, 12>(lead0 + lsz + (size_t)j * 12, pv);
+  }
+  const int ne = R.K * 19;
+  T* Xl = L.Xs + R.g0 * 19;
+  MsPred<T> Q;
+  double* img = A.pred_io ? A.pred_io + ((size_t)rod * W + wave) * MS_PRED_ROWS * WAVE : nullptr;
+  if (img && A.pred_load) ms_pred_load<T>(Q, img, lane);
+  else mswp_init<T>(Q, lane, ne, R.g0, N, P, s0, sp, A.prev_init != nullptr, A.predictor);
+  MsSolveArgs<T> S;
+  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  S.kappa = Q.kappa;
+  T Gguess = (wave == 0 && lane < 6) ? A.G[rod * 6 + lane] : T(0);
+  const T* ctl = A.ctl + rod * A.T_steps * 4;
+  __syncthreads();
+  for (int64_t t = 0; t < A.T_steps; ++t) {
+    const T* cur = lead0 + (int)(t & 1) * lsz;        // leading slots of the state at time level t
+    T* prv = lead0 + (int)((t + 1) & 1) * lsz;        // ... of level t - 1; the storing sweep overwrites them with level t + 1
+    // BDF2 history (knode.py:74-75), raw terms only
+    for (int j = threadIdx.x; j < N; j += WAVE * W) {
+      T cv[12], pv[12], hv[12];
+      load_hist_vec<T, 12>(cur + (size_t)j * 12, cv);
+      load_hist_vec<T, 12>(prv + (size_t)j * 12, pv);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[k] + A.hc2 * pv[k];
+      store_vec<T, 12>(L.hist + (size_t)j * HS_LEAN, hv);
+    }
+    {  // z of the last grid point is never touched by a sweep
+      const T* cl = cur + (size_t)(N - 1) * 12;
+      S.vlast = {cl[6], cl[7], cl[8]};
+      S.ulast = {cl[9], cl[10], cl[11]};
+    }
+    __syncthreads();
+    V3<T> fconst;
+    {
+      V3<T> tf{T(0), T(0), T(0)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // cosserat_ode.py:195
+        const T tt = ctl[t * 4 + k];
+        tf.x += tt * L.cold[CD_TDIRS + k * 3 + 0];
+        tf.y += tt * L.cold[CD_TDIRS + k * 3 + 1];
+        tf.z += tt * L.cold[CD_TDIRS + k * 3 + 2];
+      }
+      fconst = {L.cold[CD_RHOAG] + tf.x, L.cold[CD_RHOAG + 1] + tf.y, L.cold[CD_RHOAG + 2] + tf.z};
+    }
+    const int64_t inx = A.ring ? (t + 1) % 3 : t + 1;
+    S.out_rod = A.states + inx * A.slot_elems + rod * rod_elems;
+    S.tip = A.tip ? A.tip + (rod * A.T_steps + t) * 3 : nullptr;
+    S.lead12 = prv;
+    int order = Q.next_order;
+    int status, it;
+    while (true) {
+      mswp_guess<T>(Q, order, lane, ne, wave == 0, L.cold, Xl);
+      wave_sync();
+      if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
+      __syncthreads();
+      status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
+      if (status == KR_ST_CONVERGED || order == 0) break;
+      order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
+      __syncthreads();
+    }
+    if (wave == 0 && lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
+    mswp_update<T, W>(Q, order, status, A.predictor, lane, wave, ne, Xl, L.red);
+    if (wave == 0 && lane < 6) Gguess = L.Xs[0 * 19 + 7 + lane];
+    __syncthreads();  // the storing lanes' leading slots (and Xs) before the next step reads them
+  }
+  if (wave == 0 && lane < 6) A.G[rod * 6 + lane] = Gguess;
+  if (img) {
+    Q.kappa = S.kappa;
+    ms_pred_save<T>(Q, img, lane);
+  }
+}
+
+template <typename T, bool DIAG, int W>
+static int launch_msw_sim_inst(const RodConst<T>& P, const SimArgs<T>& a, hipStream_t s) {
+  auto kern = msw_sim_kernel<T, DIAG, W>;
+  const size_t smem = sizeof(T) * msw_sim_lds_elems<T, W>(P.N);
+  static thread_local size_t configured = 0;
+  if (smem > 48 * 1024 && smem > configured) {
+    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * W), smem, s, P, a);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+// kr_simulate_batch with several wavefronts per rod: 0 launched (all steps in one launch), 1 does not apply
+template <typename T>
+static int launch_msw_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s) {
+  const RodConst<T>& P = consts<T>(h);
+  const size_t bytes = sizeof(T) * (W == 2 ? msw_sim_lds_elems<T, 2>(P.N) : msw_sim_lds_elems<T, 4>(P.N));
+  if (bytes > (size_t)h->lds_limit) return 1;
+  const int64_t per_cu = (int64_t)((size_t)h->lds_limit / bytes);
+  if (a.B > 256 * per_cu) return 1;  // (a second round of workgroups would wait for the first to finish all steps)
+  h->last_waves_per_rod = W;
+  if (W == 2) return P.diag ? launch_msw_sim_inst<T, true, 2>(P, a, s) : launch_msw_sim_inst<T, false, 2>(P, a, s);
+  return P.diag ? launch_msw_sim_inst<T, true, 4>(P, a, s) : launch_msw_sim_inst<T, false, 4>(P, a, s);
+}
+
 template <typename T, int W>
 static size_t msw_lds_bytes(int N) { return sizeof(T) * msw_lds_elems<T, W>(N); }
 
-// wavefronts per rod this call should use (0: not this kernel).  Auto: batches that leave SIMDs idle - long rods (no
-// persistent form) and rods of 80 grid points and more; the option "waves_per_rod" forces 1 / 2 / 4.
+// wavefronts per rod this call should use (0: not this kernel).  Auto: batches that leave SIMDs idle (one wavefront per
+// SIMD at most, B W <= 1024); the option "waves_per_rod" forces 1 / 2 / 4.  Measured, fp64, us per step
+// (tools/msw_timing.py; persistent = all steps of kr_simulate_batch in one launch):
+//     N    B    persistent W=1   per step W=4   persistent W=2   persistent W=4
+//    40  256        20.5            25.5            18.2             18.6
+//    64  256        26.9             -              21.4             20.3
+//   100  256        35.9            30.3            26.9             23.6
+//   100  512        36.5             -              29.5              -
+//   128  256     (47.7 per step)    32.6            31.1             25.6
+//   400  256    (115 per step)      59.5             -                -      (no persistent form: LDS)
 template <typename T>
 int step_waves_per_rod(kr_handle* h, int scheme, int use_nn, int64_t B, int mode) {
   const RodConst<T>& P = consts<T>(h);
   if (use_nn || scheme != KR_EULER || mode != 0 || h->ms_mode == 0) return 0;
-  auto fits = [&](int W, size_t bytes) {
-    if (P.N - 1 < 2 * (4 + 3 * (W - 1))) return false;
+  auto fits_bytes = [&](size_t bytes) {
     if (bytes > (size_t)h->lds_limit) return false;
-    const int64_t per_cu = (int64_t)((size_t)h->lds_limit / bytes);
-    return B <= 256 * per_cu && B * W <= 2048;
+    return B <= 256 * (int64_t)((size_t)h->lds_limit / bytes);
   };
-  const size_t b2 = msw_lds_bytes<T, 2>(P.N), b4 = msw_lds_bytes<T, 4>(P.N);
+  auto fits = [&](int W) {  // the one-launch-per-step kernel
+    if (P.N - 1 < 2 * (4 + 3 * (W - 1)) || B * W > 1024) return false;
+    return fits_bytes(W == 2 ? msw_lds_bytes<T, 2>(P.N) : msw_lds_bytes<T, 4>(P.N));
+  };
+  auto fits_sim = [&](int W) {  // ... and its persistent form
+    return fits_bytes(sizeof(T) * (W == 2 ? msw_sim_lds_elems<T, 2>(P.N) : msw_sim_lds_elems<T, 4>(P.N)));
+  };
   if (h->waves_per_rod == 1) return 0;
-  if (h->waves_per_rod == 2) return fits(2, b2) ? 2 : 0;
-  if (h->waves_per_rod == 4) return fits(4, b4) ? 4 : 0;
+  if (h->waves_per_rod == 2) return fits(2) ? 2 : 0;
+  if (h->waves_per_rod == 4) return fits(4) ? 4 : 0;
   if (P.N <= MS_NPL * WAVE) {
-    // the persistent one-wavefront kernel serves these; four wavefronts per rod, one launch per step, are faster
-    // only when three quarters of the chip would idle otherwise and the rod is long enough for the shorter chains to
-    // pay for the distributed condensation (tools/msw_timing.py, B = 256: N = 100 30.3 against 35.8 us per step,
-    // N = 40 25.5 against 20.3)
-    if (P.N >= 80 && B * 4 <= 1024 && fits(4, b4)) return 4;
+    // the persistent one-wavefront kernel serves these: several wavefronts only where their own persistent form fits
+    // and the rod is long enough for the shorter chains to pay for the distributed condensation
+    if (P.N >= 56 && fits(4) && fits_sim(4)) return 4;
+    if (P.N >= 32 && fits(2) && fits_sim(2)) return 2;
     return 0;
   }
-  if (B * 4 <= 1024 && fits(4, b4)) return 4;
-  if (B * 2 <= 1024 && fits(2, b2)) return 2;
+  if (fits(4)) return 4;
+  if (fits(2)) return 2;
   return 0;
 }
 template <typename T, bool DIAG, int W>

@@ -26,6 +26,13 @@ def waves(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=[2, 4])
+def waves_persistent(request, monkeypatch):
+    """The persistent form (all steps of kr_simulate_batch in one launch, leading slots of the states kept in LDS)."""
+    set_mode_env(monkeypatch, "persistent", waves_per_rod=request.param)
+    return request.param
+
+
 def _n400_case(P):
     if P == "1_0":
         g = load_golden("sim_n400")
@@ -185,6 +192,88 @@ def test_step_batch(torch_cuda, waves):
         assert bad == 0 and rel_l2(got, tip_c) < 1e-8
 
 
+def _assert_persistent(h, waves):
+    assert h.get_option("last_sim_path") == 2 and h.get_option("last_waves_per_rod") == waves
+
+
+@pytest.mark.parametrize("N,mod", [(27, None), (100, None), (100, "dampstiff"), (131, None), (200, "dampstiff")])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_persistent_vs_oracle(torch_cuda, waves_persistent, N, mod, dtype):
+    """The persistent several-wavefront kernel: 12 steps against the C oracle (fp64 <= 1e-8, fp32 inside the 1e-5
+    contract), full trajectory stored, status reported per step."""
+    import cosserat_oracle as orc
+    import cosserat_oracle_c as oc
+    from knode import simulate_batch
+    W = waves_persistent
+    if N - 1 < 2 * (4 + 3 * (W - 1)):
+        pytest.skip("too few grid points for this many sub-intervals")
+    r = make_robot(mod, N)
+    T = 12
+    ctl = np.array(orc.calc_controls("sine", 2.0, r.del_t, T))
+    out = simulate_batch(r, ctl[None], dtype=dtype)
+    _assert_persistent(r._native(), W)
+    assert np.all(out["status"] == 0)
+    tip_c, _, bad = oc.simulate(orc.params_for(mod, N), ctl)
+    assert bad == 0
+    assert rel_l2(out["tip"][0], tip_c) < (1e-8 if dtype == "f64" else 1e-5)
+    assert rel_l2(out["traj"][0, 1:, :3, -1], tip_c) < (1e-8 if dtype == "f64" else 1e-5)  # the stored states, too
+
+
+def test_persistent_chunked_and_ring(torch_cuda, waves_persistent):
+    """A trajectory advanced by several calls with "keep_predictor" (one predictor image per wavefront) and in a 3-slot
+    ring equals the trajectory of one call; a rod's result does not depend on the batch around it; the one-launch-per-
+    step kernel gives the same states to rounding."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    W = waves_persistent
+    r = make_robot(None, 100)
+    h = r._native()
+    dt = torch.float64
+    B, T = 6, 30
+    ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 5), device=DEV).contiguous()
+    full = h.new_state(B, dt, n_slots=T + 1)
+    h.init_straight(full[0])
+    G0 = torch.zeros((B, 6), dtype=dt, device=DEV)
+    h.simulate(ctl, full, G0)
+    _assert_persistent(h, W)
+    # chunks of 10 steps in a ring, predictor handed over
+    h.set_option("keep_predictor", 0)
+    h.set_option("keep_predictor", 1)
+    ring = h.new_state(B, dt, n_slots=3)
+    h.init_straight(ring[0])
+    G = torch.zeros((B, 6), dtype=dt, device=DEV)
+    tips = []
+    prev = None
+    cur_slot = 0
+    for c in range(3):
+        st = ring[[cur_slot, (cur_slot + 1) % 3, (cur_slot + 2) % 3]].contiguous()
+        tip = torch.empty((B, 10, 3), dtype=dt, device=DEV)
+        h.simulate(ctl[:, 10 * c:10 * c + 10].contiguous(), st, G, ring=True, tip=tip, prev_init=prev)
+        _assert_persistent(h, W)
+        tips.append(tip)
+        ring = st
+        cur_slot = 10 % 3          # after 10 steps the newest state sits in slot 10 % 3 of the rotated ring
+        prev = st[(cur_slot + 2) % 3].clone()
+    h.set_option("keep_predictor", 0)
+    got = torch.cat(tips, dim=1)
+    want = torch.stack([h.tip(full[t + 1]) for t in range(T)], dim=1)
+    assert float((got - want).abs().max()) < 1e-8 * float(want.abs().max())
+    # batch independence
+    one = h.new_state(1, dt, n_slots=T + 1)
+    h.init_straight(one[0])
+    h.simulate(ctl[2:3].contiguous(), one, torch.zeros((1, 6), dtype=dt, device=DEV))
+    assert torch.equal(one[T][0], full[T][2])
+    # the one-launch-per-step kernel
+    h.set_option("persistent", 0)
+    ps = h.new_state(B, dt, n_slots=T + 1)
+    h.init_straight(ps[0])
+    h.simulate(ctl, ps, torch.zeros((B, 6), dtype=dt, device=DEV))
+    assert_path(h, 1, W)
+    h.set_option("persistent", 1)
+    assert float((ps[T] - full[T]).abs().max()) < 1e-9 * float(full[T].abs().max())
+    assert float(full[T][..., 25:].abs().max()) == 0.0
+
+
 def test_iteration_cap_is_reported(torch_cuda, waves):
     """A step that runs into the iteration cap ends (every wavefront of the workgroup leaves the loop together), streams
     its last iterate and reports status 1; with enough iterations the same inputs converge."""
@@ -209,8 +298,9 @@ def test_iteration_cap_is_reported(torch_cuda, waves):
 
 
 def test_auto_choice(torch_cuda, monkeypatch):
-    """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512, one beyond;
-    N = 100 takes four up to B = 256 and the persistent one-wavefront kernel beyond; N = 40 always the persistent one."""
+    """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512, one beyond (one
+    launch per step: no persistent form fits); N = 100 runs the persistent several-wavefront kernel with four up to
+    B = 256, two up to B = 512 and the persistent one-wavefront kernel beyond; N = 20 always the latter."""
     torch = torch_cuda
     set_mode_env(monkeypatch, "persistent", waves_per_rod=0)
 
@@ -229,9 +319,9 @@ def test_auto_choice(torch_cuda, monkeypatch):
         run(h, B)
         assert_path(h, 1, want)
     h = make_robot(None, 100)._native()
-    for B, path, want in ((4, 1, 4), (256, 1, 4), (257, 2, 1)):
+    for B, want in ((4, 4), (256, 4), (257, 2), (512, 2), (513, 1)):
         run(h, B)
-        assert_path(h, path, want)
-    h = make_robot(None, 40)._native()
+        assert h.get_option("last_sim_path") == 2 and h.get_option("last_waves_per_rod") == want, (B, want)
+    h = make_robot(None, 20)._native()
     run(h, 4)
-    assert_path(h, 2)
+    assert h.get_option("last_sim_path") == 2 and h.get_option("last_waves_per_rod") == 1

@@ -33,7 +33,8 @@ def timed_sim(r, B, T, dtype, seed, warm=60):
         h.simulate(ctl[:, warm:].contiguous(), st, Gs, ring=True, status=status, prev_init=st[2])
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     path = h.get_option("last_sim_path")
-    return best / T, int((status != 0).sum()), (f"{path}, {h.get_option('last_waves_per_rod')} wavefronts per rod" if path == 1 else path)
+    w = h.get_option("last_waves_per_rod")
+    return best / T, int((status != 0).sum()), (f"{path}, {w} wavefronts per rod" if (path == 1 or w > 1) else path)
 
 print("cfg1  single rod, N=20, 200 steps, constant tensions (reference fixture sim_cfg1)")
 g = G("sim_cfg1"); r = robot(20)

@@ -32,11 +32,11 @@ for N, B in zip(args[0::2], args[1::2]):
     h.set_option("persistent", 0); h.set_option("keep_predictor", 1)
     for dt in (torch.float64, torch.float32):
         ref = None
-        for W in (0, 1, 2, 4):  # 0: the persistent kernel (one wavefront per rod, all steps in one launch) where it applies
-            h.set_option("persistent", 1 if W == 0 else 0)
-            h.set_option("waves_per_rod", max(W, 1))
+        for persist, W in ((1, 1), (0, 1), (0, 2), (0, 4), (1, 2), (1, 4)):  # persistent: all steps in one launch
+            h.set_option("persistent", persist)
+            h.set_option("waves_per_rod", W)
             s, bad, last = timed(h, B, 60, dt)
-            got = "persistent" if h.get_option("last_sim_path") == 2 else h.get_option("last_waves_per_rod")
+            got = f"{'persistent' if h.get_option('last_sim_path') == 2 else 'per step  '} {h.get_option('last_waves_per_rod')}"
             ref = last if ref is None else ref
-            print(f"N={N:4d} B={B:5d} {str(dt):14s} W={W} (ran {got})  {s*1e6:8.1f} us/step  {B/s/1e6:6.2f} M rod-steps/s  "
+            print(f"N={N:4d} B={B:5d} {str(dt):14s} {('persistent' if persist else 'per step  ')} W={W} (ran {got})  {s*1e6:8.1f} us/step  {B/s/1e6:6.2f} M rod-steps/s  "
                   f"unconverged {bad}  max|d| vs W=1 {np.abs(last-ref).max():.2e}", flush=True)

@@ -51,6 +51,8 @@ for N, B, T in ((100, 512, 240), (40, 512, 240), (130, 192, 120), (257, 128, 80)
                 if N <= 128: variants.append(("multi, persistent", {"ms_mode": 1, "persistent": 1, "waves_per_rod": 1}))
                 if N - 1 >= 14: variants.append(("2 wavefronts", {"ms_mode": 1, "persistent": 0, "waves_per_rod": 2}))
                 if N - 1 >= 26: variants.append(("4 wavefronts", {"ms_mode": 1, "persistent": 0, "waves_per_rod": 4}))
+                if N - 1 >= 14 and N <= 257: variants.append(("2 wavefronts, persistent", {"ms_mode": 1, "persistent": 1, "waves_per_rod": 2}))
+                if N - 1 >= 26 and N <= 257: variants.append(("4 wavefronts, persistent", {"ms_mode": 1, "persistent": 1, "waves_per_rod": 4}))
                 line = []
                 for name, opts in variants:
                     tip, bad, path = run(h, ctl, dt, opts)
