@@ -154,6 +154,46 @@ __device__ __forceinline__ double msw_sum(double v, double* red, int wave, int l
   return s;
 }
 
+// K sums / K maxima at once (one pair of barriers; red holds W * 32 elements of T >= W * K doubles for K <= 9 ... 16)
+template <int W, int K>
+__device__ __forceinline__ void msw_sum_n(double (&v)[K], double* red, int wave, int lane) {
+  static_assert(K <= 16, "scratch of the workgroup reductions");
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum_f64(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = red[k];
+#pragma unroll
+    for (int w = 1; w < W; ++w) s += red[w * K + k];
+    v[k] = s;
+  }
+  __syncthreads();
+}
+template <int W, int K>
+__device__ __forceinline__ void msw_max_n(float (&v)[K], float* red, int wave, int lane) {
+  static_assert(K <= 16, "scratch of the workgroup reductions");
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_max_nonneg(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float m = red[k];
+#pragma unroll
+    for (int w = 1; w < W; ++w) m = fmaxf(m, red[w * K + k]);
+    v[k] = m;
+  }
+  __syncthreads();
+}
+
 // two maxima at once (one pair of barriers)
 template <int W>
 __device__ __forceinline__ void msw_max2(float& a, float& b, float* red, int wave, int lane) {
@@ -289,8 +329,7 @@ __device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status,
         Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
       }
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Sn[k] = msw_sum<W>(Sn[k], redd, wave, lane);
+    msw_sum_n<W, 9>(Sn, redd, wave, lane);
     const double lam = 1e-12;
     double a6[3][4] = {{Sn[0] * (1 + lam), Sn[1], Sn[2], Sn[6] + lam * Sn[0]},
                        {Sn[1], Sn[3] * (1 + lam), Sn[4], Sn[7] + lam * Sn[3]},
@@ -313,7 +352,12 @@ __device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status,
   const int pmax = Q.avail < predictor ? Q.avail : (predictor < MS_HLEV ? predictor : MS_HLEV - 1);
   float em[MS_HLEV];
 #pragma unroll
-  for (int p = 0; p < MS_HLEV; ++p) em[p] = poly_eval ? msw_max<W>(err[p], redf, wave, lane) : 3.0e38f;
+  for (int p = 0; p < MS_HLEV; ++p) em[p] = err[p];
+  if (poly_eval) msw_max_n<W, MS_HLEV>(em, redf, wave, lane);  // (wave-uniform condition: every wavefront takes it)
+  else {
+#pragma unroll
+    for (int p = 0; p < MS_HLEV; ++p) em[p] = 3.0e38f;
+  }
   int nxt = 0;
   float eb = em[0];
 #pragma unroll
