@@ -1,4 +1,5 @@
-// kr_msw_impl.hpp - multiple shooting with SEVERAL wavefronts per rod (one time step per launch).
+// kr_msw_impl.hpp - multiple shooting with SEVERAL wavefronts per rod: msw_step_kernel (one time step per launch)
+// and msw_sim_kernel (all steps of kr_simulate_batch in one launch).
 //
 // kr_ms_impl.hpp gives a rod one wavefront and P = 4 sub-intervals; the dependent chain of a sweep is then
 // (N - 1) / 4 grid points long and a batch keeps B of the chip's 1024 SIMDs busy.  Long rods in small batches
@@ -18,10 +19,11 @@
 //   * back-substitution: every wavefront forms dY at its first interval from X^(w) and dG, its inner ones from L_k.
 // The p rows (no equation reads p) are accumulated afterwards from all intervals, like in the one-wavefront kernel.
 // Stopping rule, storing sweep prediction, start-value predictor (one MsPred per wavefront over its own unknowns, the
-// decisions reduced over the workgroup) are those of kr_ms_impl.hpp; the chord check is not used here.
+// decisions reduced over the workgroup) and the residual test of a storing sweep are those of kr_ms_impl.hpp; the chord
+// check is not used here.
 //
 // History records are the 12 raw BDF2 terms only (q_h w_h v_h u_h); av / au are re-derived per evaluation (6 FMAs), so
-// that two N = 400 rods fit the LDS of a CU in fp64.  Euler sweeps, MLP off (what long rods in small batches run).
+// that two N = 400 rods fit the LDS of a CU in fp64.  Euler sweeps, MLP off (what small batches and long rods run).
 #pragma once
 // (included by kr_ms_impl.hpp, after its definitions)
 
