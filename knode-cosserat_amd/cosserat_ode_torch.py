@@ -468,7 +468,9 @@ class CosseratRodTorch:
         return dys, z
 
     def ODE(self, y, yh, zh, tendon_forces):
-        """Single grid point, cosserat_ode_torch.py:137-214."""
+        """Single grid point, cosserat_ode_torch.py:137-214.  (Values as the reference; gradients into the inputs, when
+        asked for, are those of ODE_parallel - the reference's single-point graph is cut at R(h) and at the
+        quaternion-rate matrix, which only ``getResidualEuler`` reproduces: see ``_point_map_graph``.)"""
         dys, z = self.ODE_parallel(y.reshape(1, 19), yh.reshape(1, 19), zh.reshape(1, 6), tendon_forces.reshape(1, 3))
         return dys[0], z[0]
 
