@@ -279,6 +279,13 @@ def main():
         rod_steps = world * B * K
         path = h.get_option("last_sim_path")  # 2: the K steps ran as one persistent launch
         persistent = path == 2
+        wpr = h.get_option("last_waves_per_rod")
+        if wpr > 1:  # small batches: several wavefronts per rod (kr_msw_impl.hpp)
+            kernel_name = (f"kr::msw_sim_kernel (persistent, {wpr} wavefronts per rod)" if persistent
+                           else f"kr::msw_step_kernel ({wpr} wavefronts per rod)")
+        else:
+            kernel_name = ("kr::step_kernel", "kr::ms_step_kernel",
+                           "kr::ms_sim_kernel (persistent, all K steps in one launch)")[path] if path in (0, 1, 2) else "?"
         # SURVEY 8d algorithmic bytes per rod-step: state written every step (25 N + 4) s in the persistent
         # form (history never leaves the CU); (75 N + 16) s when every step is its own launch
         per_rod_step = (25 * N + 4) * esize if persistent else (75 * N + 16) * esize
@@ -332,8 +339,7 @@ def main():
                 "hbm": {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes,
                         "algorithmic_bytes_per_rod_step": per_rod_step},
-                "kernel": ("kr::ms_sim_kernel (persistent, all K steps in one launch)", "kr::ms_step_kernel",
-                           "kr::step_kernel")[2 - path] if path in (0, 1, 2) else "?",
+                "kernel": kernel_name,
                 "kernel_ms": round(kernel_ms, 4),
                 "launches": launches,
                 "profile": {"hbm": prof_hbm and prof_hbm["_file"], "sq": prof_sq and prof_sq["_file"]},
