@@ -1348,8 +1348,12 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
 // ---------------------------------------------------------------------------
 constexpr int MS_NPL = 2;  // grid points per lane held in registers by the persistent kernel (N <= 128)
 
-template <typename T, bool DIAG, int SCHEME, int HS, bool NN>
-__global__ __launch_bounds__(WAVE * MS_WPB) void ms_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A, const MlpDev<T> M) {
+// OCC: workgroups the register allocation must leave room for on a CU (__launch_bounds__).  With OCC = 2 the fp32
+// instantiation runs two wavefronts per SIMD - two rods - whose issue-bound sweeps and latency-bound algebra overlap:
+// +25 % (N = 100) to +37 % (N = 64) at B >= 2048 (tools/occ_probe.py), -3 % at B = 1024 where every SIMD has one
+// wavefront anyway (68 spilled registers).  In fp64 a rod needs 37.8 KB of LDS: four per CU, one per SIMD.
+template <typename T, bool DIAG, int SCHEME, int HS, bool NN, int OCC = 1>
+__global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A, const MlpDev<T> M) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = Pc.N;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1563,9 +1567,9 @@ static int launch_ms(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a,
   h->last_sim_path = 1;
   return use_nn ? launch_ms_nn<T, true>(h, scheme, a, s) : launch_ms_nn<T, false>(h, scheme, a, s);
 }
-template <typename T, bool DIAG, int SCHEME, bool NN>
+template <typename T, bool DIAG, int SCHEME, bool NN, int OCC = 1>
 static int launch_ms_sim_inst(const RodConst<T>& P, const MlpDev<T>& M, const SimArgs<T>& a, hipStream_t s) {
-  auto kern = ms_sim_kernel<T, DIAG, SCHEME, hs_phys<T>(), NN>;
+  auto kern = ms_sim_kernel<T, DIAG, SCHEME, hs_phys<T>(), NN, OCC>;
   const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, true, NN);
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
@@ -1601,8 +1605,14 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
   if (P.N - 1 < 2 * MS_P || P.N > MS_NPL * WAVE) return 1;
   if (ms_lds_bytes<T, hs_phys<T>()>(P.N, true) > (size_t)h->lds_limit) return 1;
   if (h->ms_mode != 1 && a.B > (int64_t)h->ms_batch_limit) return 1;
-  if (scheme == KR_EULER)
+  if (scheme == KR_EULER) {
+    if constexpr (sizeof(T) == 4) {
+      // fp32, more rods than SIMDs, and two workgroups fit the LDS of a CU: the two-wavefronts-per-SIMD instantiation
+      if (P.diag && a.B > 1024 && 2 * ms_lds_bytes<T, hs_phys<T>()>(P.N, true) <= (size_t)h->lds_limit)
+        return launch_ms_sim_inst<T, true, KR_EULER, false, 2>(P, M, a, s);
+    }
     return P.diag ? launch_ms_sim_inst<T, true, KR_EULER, false>(P, M, a, s) : launch_ms_sim_inst<T, false, KR_EULER, false>(P, M, a, s);
+  }
   if (scheme == KR_RK4)
     return P.diag ? launch_ms_sim_inst<T, true, KR_RK4, false>(P, M, a, s) : launch_ms_sim_inst<T, false, KR_RK4, false>(P, M, a, s);
   set_error("unknown scheme");
