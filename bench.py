@@ -115,11 +115,15 @@ def cpu_baseline(N, del_t, B, sample_steps, rods=None):
 def _cpu_worker(args):
     N, ctl = args
     os.environ["OMP_NUM_THREADS"] = "1"
+    import warnings
     import numpy as np
     import cosserat_oracle as orc
     D = orc.params_for(None, N).derived()
-    # the oracle mirrors knode.simulate: T controls -> T solves, last one dropped from the output
-    traj = orc.simulate(D, np.vstack([ctl, ctl[-1:]]), solver="fsolve")
+    # the oracle mirrors knode.simulate: T controls -> T solves, last one dropped from the output.  Its fsolve probes
+    # overflow on the way (the reference's does too): keep that off stderr, the JSON line must be the last thing printed
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        traj = orc.simulate(D, np.vstack([ctl, ctl[-1:]]), solver="fsolve")
     return traj[1:, :3, -1]
 
 
@@ -145,6 +149,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+
+    # ---- CPU leg FIRST: it forks a process pool, and a process that has initialised the GPU must not be forked (nor
+    # ever exec'd).  Nothing above touches HIP: importing torch / loading libknode_rod.so does not, and the parameter
+    # presets are host-side library calls.
+    cpu_leg = None
+    if world == 1 and not args.no_cpu:
+        probe = CosseratRod(use_fsolve=True)
+        setup_robot(probe)
+        pre0 = max(0, SETTLE_TOTAL - args.warmup) + args.warmup
+        Tc = min(pre0 + args.steps, max(50, pre0 + 20))
+        cb, cpu_tips = cpu_baseline(args.nodes_per_rod, probe.del_t, args.batch, Tc)
+        try:
+            cbc = cpu_baseline_c(args.nodes_per_rod, probe.del_t, args.batch)
+        except Exception as e:  # the C restatement is optional test infrastructure (needs gcc or its prebuilt .so)
+            cbc = {"error": str(e)}
+        cpu_leg = (Tc, cb, cpu_tips, cbc)
     # one rank per GPU; KR_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the
     # multi-rank code path on a 1-GPU box (collectives then run on CPU tensors)
     backend = os.environ.get("KR_BENCH_BACKEND", "nccl")
@@ -228,7 +248,8 @@ def main():
             h2.simulate(ramp_ctl, ramp_st, ramp_g, ring=True, scheme=1)  # KR_RK4
         torch.cuda.synchronize()
 
-    ramp(0.5)
+    RAMP_A, RAMP_B = 0.5, 0.3
+    ramp(RAMP_A)
     cold = None
     if not args.no_cpu:
         cold = {}
@@ -246,7 +267,7 @@ def main():
     pre_states = h.new_state(B, tdt, n_slots=pre + 1) if pre else None
     states = h.new_state(B, tdt, n_slots=3)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ramp(0.3)  # (on the second handle: the predictor image of `h` is not touched)
+    ramp(RAMP_B)  # (on the second handle: the predictor image of `h` is not touched)
     if pre:
         h.init_straight(pre_states[0])
         h.simulate(ctl_pre, pre_states, G, tip=tip_pre)
@@ -304,6 +325,7 @@ def main():
             per_unit = prof_hbm["hbm_bytes_per_launch_corrected"] / (B * prof_hbm.get("steps_per_launch", 1))
             traffic = int(per_unit * units_per_launch)
         valu_issue = None
+        instr_per_unit = None
         if prof_sq and prof_sq.get("per_launch", {}).get("SQ_INSTS_VALU") and prof_sq.get("steps_per_launch"):
             instr_per_unit = prof_sq["per_launch"]["SQ_INSTS_VALU"] / (B * prof_sq["steps_per_launch"])
             # wave-instructions x 4 issue cycles over the SIMD-cycles of the launch (B <= 1024: one wavefront per SIMD)
@@ -316,6 +338,7 @@ def main():
             "steps": K,
             "warmup": W,
             "settle_steps": settle,
+            "ramp_s": RAMP_A + RAMP_B,
             "ms_per_step": round(elapsed / K * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -334,7 +357,12 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(tf_achieved / FP64_VALU_PEAK_TF, 5),
                 "traffic": traffic,
+                "traffic_scaled_from_profile": traffic,
+                "traffic_note": "PMC HBM bytes per rod-step of the committed profile (profile.hbm) x the rod-steps of "
+                                "this launch - not a counter pass of this run",
                 "algorithmic_flops_per_rod_step": flops_per_rod_step,
+                "achieved_is": "nominal: SURVEY 8d formula flops (k = 3 FD-Newton iterations), not executed flops",
+                "executed_valu_insts_per_rod_step": instr_per_unit and round(instr_per_unit, 1),
                 "valu_issue_frac": valu_issue,
                 "hbm": {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes,
@@ -354,9 +382,8 @@ def main():
             out["cold_start"] = {"unit": "rod-steps/s", **cold,
                                  "note": "T steps from the straight rod in one call, no warm-up, no predictor hand-over "
                                          "(SURVEY 8d cfg3: T=64, cfg2: T=200), best of 3"}
-        if world == 1 and not args.no_cpu:
-            Tc = min(pre + K, max(50, pre + 20))
-            cb, tips = cpu_baseline(N, robot.del_t, B, Tc)
+        if cpu_leg is not None:
+            Tc, cb, tips, cbc = cpu_leg
             # tip parity of the TIMED batch against the oracle: same rods, same steps (untimed + first timed ones)
             gpu_tips = torch.cat([tip_pre[:, :pre], tip], dim=1)[: len(tips), :Tc].double().cpu().numpy()
             errs = [float(np.linalg.norm(gpu_tips[b] - tips[b]) / np.linalg.norm(tips[b])) for b in range(len(tips))]
@@ -364,10 +391,7 @@ def main():
             out["tip_check"] = {"rods": len(tips), "steps": Tc, "timed_steps_included": max(0, Tc - pre),
                                 "what": "rods 0.. of the timed batch, steps 1..steps of their trajectory"}
             out["cpu_baseline"] = cb
-            try:
-                out["cpu_baseline_c"] = cpu_baseline_c(N, robot.del_t, B)
-            except Exception as e:  # the C restatement is optional test infrastructure (needs gcc or its prebuilt .so)
-                out["cpu_baseline_c"] = {"error": str(e)}
+            out["cpu_baseline_c"] = cbc
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -199,6 +199,14 @@ int kr_state_tip(kr_handle* h, int64_t B, const void* state, void* tip, int dtyp
 int kr_residual_batch(kr_handle* h, int64_t B, int scheme, const void* G, const void* state_prev,
                       const void* state_cur, void* state_next, const void* tensions, void* r, int use_nn,
                       int hist_is_explicit, int dtype, void* stream);
+/* getResidualRK4 with the CALLER'S midpoint histories (cosserat_ode.py:215-255: stages 2 and 3 read
+ * yh_int[:, j], zh_int[:, j], lines 225 and 233-234).  hist holds yh, zh and hist_mid holds yh_int, zh_int, both
+ * packed like a state ([B][N][KR_SLOTS]; record j of hist_mid belongs to the midpoint between grid points j and
+ * j + 1, record N-1 is not read).  hist_mid == NULL gives kr_residual_batch(..., hist_is_explicit = 1), i.e. the
+ * linear interpolation knode.simulate hands over (knode.py:80-81).  scheme must be KR_RK4 when hist_mid is given
+ * (the Euler sweep ignores the midpoints, cosserat_ode.py:188-213). */
+int kr_residual_mid_batch(kr_handle* h, int64_t B, int scheme, const void* G, const void* hist, const void* hist_mid,
+                          void* state_next, const void* tensions, void* r, int use_nn, int dtype, void* stream);
 
 /* ---- one implicit time step -------------------------------------------- */
 /* Body of the loop in knode.simulate (knode.py:70-100) for B rods: BDF2

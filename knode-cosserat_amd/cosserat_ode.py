@@ -89,17 +89,22 @@ class CosseratRod:
     # ------------------------------------------------------------------
     # parameters
     # ------------------------------------------------------------------
-    def _params(self) -> kn.KrParams:
+    def _params(self, live_vstar=False) -> kn.KrParams:
+        # The device derives Kse_vstar from vstar on every push.  In the reference Kse_vstar only changes inside
+        # compute_intermediate_terms() (cosserat_ode.py:75), while estimate_state.py:201 overwrites robot.vstar
+        # without recomputing it - so the compute paths see the vstar of the last compute_intermediate_terms().
+        vstar = self.vstar if live_vstar or getattr(self, "_vstar_derived", None) is None else self._vstar_derived
         return kn.params_from_dict(dict(
             L=self.L, N=int(self.N), nn_input_history=int(bool(self.nn_input_history)), E=self.E, r=self.r,
-            rho=self.rho, vstar=self.vstar, g=self.g, Bse=self.Bse, Bbt=self.Bbt, C=self.C, del_t=self.del_t,
+            rho=self.rho, vstar=vstar, g=self.g, Bse=self.Bse, Bbt=self.Bbt, C=self.C, del_t=self.del_t,
             F_tip=self.F_tip, M_tip=self.M_tip, tendon_dirs=self.tendon_dirs, p0=self.p0, h0=self.h0, q0=self.q0,
             w0=self.w0))
 
     def compute_intermediate_terms(self):
         """Dependent parameters, reference cosserat_ode.py:58-78 (computed by
         kr_derive on the host side of the library)."""
-        d = kn.derive(self._params())
+        self._vstar_derived = np.array(self.vstar, dtype=np.float64).copy()
+        d = kn.derive(self._params(live_vstar=True))
         m3 = lambda a: np.array(a, dtype=np.float64).reshape(3, 3)
         self.A, self.G, self.ds = d.A, d.G, d.ds
         self.J, self.Kse, self.Kbt = m3(d.J), m3(d.Kse), m3(d.Kbt)
@@ -186,7 +191,7 @@ class CosseratRod:
         dys, z = h.ode_batch(t(y, 19), t(yh, 19), t(zh, 6), t(tendon_forces, 3), use_nn=self._use_nn)
         return dys[0].cpu().numpy(), z[0].cpu().numpy()
 
-    def _residual(self, scheme, G, y, z, yh, zh):
+    def _residual(self, scheme, G, y, z, yh, zh, yh_int=None, zh_int=None):
         import torch
         h = self._native()
         dev = f"cuda:{self.device}"
@@ -195,8 +200,16 @@ class CosseratRod:
         hist = h.pack(td(yh).reshape(1, 19, N), td(zh).reshape(1, 6, N))
         nxt = h.new_state(1, torch.float64)
         tens = td(np.asarray(self.tendon_tensions, dtype=np.float64).reshape(1, 4))
-        r = h.residual(td(np.asarray(G, dtype=np.float64).reshape(1, 6)), None, hist, nxt, tens, scheme=scheme,
-                       use_nn=self._use_nn, hist_is_explicit=True)
+        Gd = td(np.asarray(G, dtype=np.float64).reshape(1, 6))
+        if yh_int is not None and zh_int is not None:
+            # the caller's midpoint histories, one column per segment (cosserat_ode.py:225,233-234)
+            ym = np.zeros((19, N)); zm = np.zeros((6, N))
+            ym[:, : N - 1] = np.asarray(yh_int, dtype=np.float64)[:, : N - 1]
+            zm[:, : N - 1] = np.asarray(zh_int, dtype=np.float64)[:, : N - 1]
+            mid = h.pack(td(ym).reshape(1, 19, N), td(zm).reshape(1, 6, N))
+            r = h.residual_mid(Gd, hist, mid, nxt, tens, scheme=scheme, use_nn=self._use_nn)
+        else:
+            r = h.residual(Gd, None, hist, nxt, tens, scheme=scheme, use_nn=self._use_nn, hist_is_explicit=True)
         y_new, z_new = h.unpack(nxt)
         # in-place mutation of the caller's arrays (cosserat_ode.py:194,200-201); the last column of z
         # is never written by a sweep
@@ -213,7 +226,8 @@ class CosseratRod:
         return self._residual(kn.KR_EULER, G, y, z, yh, zh)
 
     def getResidualRK4(self, G, y, z, yh, yh_int, zh, zh_int):
-        """Classical RK4 sweep; reference cosserat_ode.py:215-255.  The midpoint
-        histories are recomputed on the device as the same linear interpolation
-        knode.simulate uses (knode.py:80-81)."""
-        return self._residual(kn.KR_RK4, G, y, z, yh, zh)
+        """Classical RK4 sweep; reference cosserat_ode.py:215-255.  Stages 2 and 3 read the
+        midpoint histories the caller passes (``yh_int[:, j]``, ``zh_int[:, j]``, reference
+        lines 225 and 233-234) - whatever they are, not a re-derived interpolation; ``None``
+        for either selects the interpolation knode.simulate forms (knode.py:80-81)."""
+        return self._residual(kn.KR_RK4, G, y, z, yh, zh, yh_int, zh_int)

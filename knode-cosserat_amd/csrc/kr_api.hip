@@ -712,6 +712,22 @@ int kr_residual_batch(kr_handle* h, int64_t B, int scheme, const void* G, const 
   return launch_step<double>(h, scheme, use_nn, a, s);
 }
 
+int kr_residual_mid_batch(kr_handle* h, int64_t B, int scheme, const void* G, const void* hist, const void* hist_mid,
+                          void* state_next, const void* tensions, void* r, int use_nn, int dtype, void* stream) {
+  KR_BATCH_PROLOGUE(B);
+  KR_CHECK_PTR(G); KR_CHECK_PTR(hist); KR_CHECK_PTR(state_next);
+  KR_CHECK_PTR(tensions); KR_CHECK_PTR(r);
+  if (hist_mid && scheme != KR_RK4) { set_error("hist_mid is read by the RK4 sweep only"); return KR_E_ARG; }
+  if (dtype == KR_F32) {
+    auto a = make_args<float>(h, B, hist, hist, state_next, const_cast<void*>(G), tensions, 4, 0, 0);
+    a.mode = 1; a.r_out = (float*)r; a.hc1 = 1.f; a.hc2 = 0.f; a.mid = (const float*)hist_mid;
+    return launch_step<float>(h, scheme, use_nn, a, s);
+  }
+  auto a = make_args<double>(h, B, hist, hist, state_next, const_cast<void*>(G), tensions, 4, 0, 0);
+  a.mode = 1; a.r_out = (double*)r; a.hc1 = 1.0; a.hc2 = 0.0; a.mid = (const double*)hist_mid;
+  return launch_step<double>(h, scheme, use_nn, a, s);
+}
+
 int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, const void* state_cur,
                   void* state_next, void* G, const void* tensions, double tol, int maxit, int32_t* status,
                   int32_t* iters, int use_nn, const void* state_prev2, int predictor, int dtype, void* stream) {

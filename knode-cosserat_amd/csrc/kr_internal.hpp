@@ -149,6 +149,9 @@ struct StepArgs {
   int pred_reset = 0;     // first step of a simulate call: build the predictor from cur / prev
   int pred_has_prev = 0;  // ... prev is a real earlier state
   int pred_limit = 0;     // the handle's "predictor" option
+  // residual mode, RK4 only: explicit midpoint histories [B][N][KR_SLOTS] (record j = between grid points j and j + 1);
+  // nullptr = the linear interpolation knode.simulate forms (knode.py:80-81)
+  const T* mid = nullptr;
 };
 template <typename T>
 int launch_step(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s);

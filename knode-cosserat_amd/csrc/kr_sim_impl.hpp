@@ -134,8 +134,8 @@ __device__ __forceinline__ RodHist<T> hist_from(const T (&hv)[HS]) {
 // history record of one grid point from the packed states of the two previous
 // time levels (knode.py:74-75): raw = hc1*cur + hc2*prev, then av / au.
 template <typename T, int HS>
-__device__ __forceinline__ void build_hist_point(const RodConst<T>& P, T hc1, T hc2, const T* __restrict__ c,
-                                                 const T* __restrict__ p, T* dst) {
+__device__ __forceinline__ void build_hist_vals(const RodConst<T>& P, T hc1, T hc2, const T* __restrict__ c,
+                                                const T* __restrict__ p, T (&hv)[HS]) {
   constexpr int NR = (HS == HS_NNH) ? 25 : 12;
   constexpr int NRP = (NR + Vec16<T>::n - 1) / Vec16<T>::n * Vec16<T>::n;  // stays inside the 28-slot record
   T cv[NRP], pv[NRP];
@@ -144,7 +144,6 @@ __device__ __forceinline__ void build_hist_point(const RodConst<T>& P, T hc1, T 
   T raw[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) raw[k] = hc1 * cv[k] + hc2 * pv[k];
-  T hv[HS];
 #pragma unroll
   for (int k = 0; k < 12; ++k) hv[k] = raw[k];
   RodHist<T> h;
@@ -163,6 +162,12 @@ __device__ __forceinline__ void build_hist_point(const RodConst<T>& P, T hc1, T 
     hv[18] = T(0);
     hv[19] = T(0);
   }
+}
+template <typename T, int HS>
+__device__ __forceinline__ void build_hist_point(const RodConst<T>& P, T hc1, T hc2, const T* __restrict__ c,
+                                                 const T* __restrict__ p, T* dst) {
+  T hv[HS];
+  build_hist_vals<T, HS>(P, hc1, hc2, c, p, hv);
   using V = typename Vec16<T>::type;
   constexpr int n = Vec16<T>::n;
   V* d = reinterpret_cast<V*>(dst);
@@ -457,8 +462,14 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
         // history, stage 4 the history of point j+1
         T hn[HS], hm[HS];
         load_hist_vec<T, HS>(C.hbase + (size_t)(j + 1) * HS, hn);
+        if (A.mid) {
+          // the caller's own midpoint histories yh_int[:, j], zh_int[:, j] (cosserat_ode.py:225,233-234)
+          const T* mp = A.mid + rod * rod_elems + (size_t)j * KR_SLOTS;
+          build_hist_vals<T, HS>(P, T(1), T(0), mp, mp, hm);
+        } else {
 #pragma unroll
-        for (int c = 0; c < HS; ++c) hm[c] = T(0.5) * (hv[c] + hn[c]);
+          for (int c = 0; c < HS; ++c) hm[c] = T(0.5) * (hv[c] + hn[c]);
+        }
         RodState<T> k2, k3, k4;
         V3<T> v2, u2;
         RodState<T> ya = state_axpy(y, P.ds * T(0.5), k1);

@@ -143,6 +143,9 @@ def simulate(robot, ctl, robot_reference=None):
         raise kn.KrError("robot and robot_reference must share N")
     if T == 0:  # np.array([initial])[:-1] in the reference
         return np.empty((0, 50, N), dtype=np.float64)
+    # side effect of the reference's loop (knode.py:71): the robot is left holding the LAST control, including the
+    # one whose solve is dropped - a following robot.getResidualEuler(...) by the caller reads it
+    robot.tendon_tensions = ctl[-1].copy()
     h = robot._native()
     dev = f"cuda:{robot.device}"
     states = h.new_state(1, torch.float64, n_slots=max(T, 2))

@@ -76,6 +76,7 @@ _PROTOS = {
     "kr_state_unpack50": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "kr_state_tip": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
     "kr_residual_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    "kr_residual_mid_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kr_step_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp, _vp, _int, _vp, _int, _int, _vp]),
     "kr_simulate_batch": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, C.c_double, _int, _vp, _int, _vp, _int, _vp]),
     "kr_next_segment_physics": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp]),
@@ -290,6 +291,15 @@ class Handle:
         check(self.lib.kr_residual_batch(self._h, B, scheme, _ptr(G), _ptr(prev), _ptr(cur), _ptr(nxt), _ptr(tensions),
                                          _ptr(r), int(bool(use_nn)), int(bool(hist_is_explicit)),
                                          dtype_code(G.dtype), _stream()))
+        return r
+
+    def residual_mid(self, G, hist, hist_mid, nxt, tensions, scheme=KR_RK4, use_nn=False):
+        """Residual sweep from explicit histories; ``hist_mid`` (may be None) = the caller's midpoint histories."""
+        import torch
+        B = G.shape[0]
+        r = torch.empty((B, 6), dtype=G.dtype, device=G.device)
+        check(self.lib.kr_residual_mid_batch(self._h, B, scheme, _ptr(G), _ptr(hist), _ptr(hist_mid), _ptr(nxt),
+                                             _ptr(tensions), _ptr(r), int(bool(use_nn)), dtype_code(G.dtype), _stream()))
         return r
 
     def mlp_eval(self, x):

@@ -620,11 +620,63 @@ def gen_small():
     save("small", **out)
 
 
+def gen_round3():
+    """Round 3: (a) getResidualRK4 with midpoint histories that are NOT the linear interpolation of yh, zh
+    (cosserat_ode.py:225,233-234 read whatever the caller passes); (b) BASELINE cfg2: rods of the
+    ``default_rng(1234)`` draw for B = 256 at N = 100, 50 steps, whose fsolve reported ier == 1 throughout."""
+    rng = np.random.default_rng(33)
+    out = {}
+    for N, mod in [(40, "default"), (100, None)]:
+        r = np_robot(mod, N)
+        y, z, yp, zp, G0, tens = converged_state(
+            r, 6, lambda T: ref_ctl.calc_controls("sine", 1.0, r.del_t, T))
+        yh = r.c1 * y + r.c2 * yp
+        zh = r.c1 * z + r.c2 * zp
+        yh_int = 0.5 * (yh[:, :-1] + yh[:, 1:])
+        zh_int = 0.5 * (zh[:, :-1] + zh[:, 1:])
+        yh_int = yh_int * (1 + 0.1 * rng.standard_normal(yh_int.shape)) + 1e-3 * rng.standard_normal(yh_int.shape)
+        zh_int = zh_int * (1 + 0.1 * rng.standard_normal(zh_int.shape)) + 1e-3 * rng.standard_normal(zh_int.shape)
+        r.tendon_tensions = tens
+        tag = f"mid_N{N}_{mod}"
+        out[f"{tag}_y"], out[f"{tag}_z"], out[f"{tag}_yp"], out[f"{tag}_zp"] = y, z, yp, zp
+        out[f"{tag}_yh_int"], out[f"{tag}_zh_int"] = yh_int, zh_int
+        out[f"{tag}_tens"] = tens
+        Gs = G0[None, :] * (1 + 0.05 * rng.standard_normal((2, 6))) + 1e-3 * rng.standard_normal((2, 6))
+        out[f"{tag}_G"] = Gs
+        rs, ys, zs = [], [], []
+        for G in Gs:
+            yy, zz = y.copy(), z.copy()
+            with np.errstate(all="ignore"):
+                rs.append(r.getResidualRK4(G, yy, zz, yh, yh_int, zh, zh_int))
+            ys.append(yy)
+            zs.append(zz)
+        out[f"{tag}_r"], out[f"{tag}_yout"], out[f"{tag}_zout"] = np.array(rs), np.array(ys), np.array(zs)
+    # cfg2
+    r = np_robot(None, 100)
+    T = 50
+    ctl_b = orc.batch_sine_controls(256, T, r.del_t, 1234)
+    rods, tips, lasts = [], [], []
+    cand = 0
+    while len(rods) < 8 and cand < 24:
+        tr, ie, _ = run_sim(r, ctl_b[cand])
+        ok = bool(np.all(ie == 1)) and bool(np.all(np.isfinite(tr)))
+        print(f"  cfg2 candidate rod {cand}: ier all 1 = {ok}")
+        if ok:
+            rods.append(cand)
+            tips.append(tr[:, :3, -1])
+            lasts.append(tr[-1, :25])
+        cand += 1
+    out.update(cfg2_rods=np.array(rods), cfg2_tip=np.array(tips), cfg2_last=np.array(lasts), cfg2_T=np.array(T),
+               cfg2_seed=np.array(1234), cfg2_B=np.array(256))
+    save("round3", **out)
+
+
 ALL = {
     "ode_kat": gen_ode_kat, "ode_torch_kat": gen_ode_torch_kat, "residual_kat": gen_residual_kat,
     "sim_cfg1": gen_sim_cfg1, "sim_n100": gen_sim_n100, "sim_n400": gen_sim_n400, "sim_misc": gen_sim_misc,
     "sim_nn": gen_sim_nn, "sim_more": gen_sim_more, "train_step": gen_train_step, "small": gen_small,
     "checkpoint": gen_checkpoint, "estimate_state": gen_estimate_state, "tres_grad": gen_tres_grad,
+    "round3": gen_round3,
 }
 
 if __name__ == "__main__":

@@ -560,5 +560,15 @@ def test_estimate_state_on_device(torch_cuda, N):
     b = eor.estimate_state(data, ctl, r3)
     for rows in (slice(0, 7), slice(13, 19), slice(7, 13), slice(19, 25)):
         assert rel_l2(a[:, rows], b[:, rows]) < 1e-9
+    # a second call on the same robots: the first one left robot.vstar at the re-estimated root strain WITHOUT
+    # recomputing Kse_vstar (estimate_state.py:201), so both calls - and a simulate in between - must see the
+    # Kse_vstar of the last compute_intermediate_terms()
+    kv = np.array(r2.Kse_vstar, dtype=np.float64).copy()
+    a2 = kest.estimate_state(data[:120], ctl[:120], r2)
+    b2 = eor.estimate_state(data[:120], ctl[:120], r3)
+    assert np.array_equal(np.asarray(r2.Kse_vstar, dtype=np.float64), kv)
+    for rows in (slice(0, 7), slice(13, 19), slice(7, 13), slice(19, 25)):
+        assert rel_l2(a2[:, rows], b2[:, rows]) < 1e-9
+        assert rel_l2(a2[:, rows], a[:120, rows]) < 1e-9  # same input rows, same Kse_vstar: same estimate
     with pytest.raises(Exception):
         kest.estimate_state(data[:, :, :-1], ctl, r2)

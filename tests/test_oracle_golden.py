@@ -267,3 +267,40 @@ def test_c_oracle_vs_numpy_oracle(mod):
     tip, tr, bad = oc.simulate(P, ctl)
     assert bad == 0
     assert np.linalg.norm(tr - want[:13, :25]) / np.linalg.norm(want[:13, :25]) < 1e-10
+
+
+# ---------------------------------------------------------------------------
+# round 3 fixtures (tests/golden/round3.npz)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["mid_N40_default", "mid_N100_None"])
+def test_rk4_residual_with_callers_midpoints(tag):
+    """getResidualRK4 reads the midpoint histories the caller passes (cosserat_ode.py:225,233-234); the fixture's
+    are NOT the linear interpolation of yh, zh."""
+    g = load_golden("round3")
+    N = int(tag.split("_")[1][1:])
+    mod = tag.split("_")[2]
+    D = orc.params_for(mod, N).derived()
+    y0, z0, yp, zp = g[f"{tag}_y"], g[f"{tag}_z"], g[f"{tag}_yp"], g[f"{tag}_zp"]
+    yh = D.c1 * y0 + D.c2 * yp
+    zh = D.c1 * z0 + D.c2 * zp
+    lin = 0.5 * (yh[:, :-1] + yh[:, 1:])
+    assert rel_l2(g[f"{tag}_yh_int"], lin) > 1e-2  # the midpoints really differ from the interpolation
+    for k, G in enumerate(g[f"{tag}_G"]):
+        y, z = y0.copy(), z0.copy()
+        r = orc.residual_rk4(D, G, y, z, yh, g[f"{tag}_yh_int"], zh, g[f"{tag}_zh_int"], g[f"{tag}_tens"])
+        assert rel_l2(y, g[f"{tag}_yout"][k]) < 1e-12
+        assert rel_l2(z, g[f"{tag}_zout"][k]) < 1e-12
+        assert np.allclose(r, g[f"{tag}_r"][k], rtol=1e-9, atol=1e-11 * np.abs(y[7:13]).max())
+
+
+def test_cfg2_rods_of_the_256_draw():
+    """BASELINE cfg2: rod 0 of the default_rng(1234) draw for B = 256 (N = 100), first 12 steps, against the
+    reference's tips - pins the oracle's control generator for the full batch size and the fixture's rod order."""
+    g = load_golden("round3")
+    assert list(g["cfg2_rods"]) == [0, 1, 3, 4, 6, 7, 8, 10] and int(g["cfg2_B"]) == 256
+    D = orc.params_for(None, 100).derived()
+    T = 12
+    ctl = orc.batch_sine_controls(256, int(g["cfg2_T"]), D.P.del_t, int(g["cfg2_seed"]))
+    with np.errstate(all="ignore"):
+        traj = orc.simulate(D, ctl[0][:T], solver="fsolve")
+    assert rel_l2(traj[:, :3, -1], g["cfg2_tip"][0][:T]) < 1e-9
