@@ -142,7 +142,9 @@ def test_cfg4_shard_training_step(torch_cuda, N):
     tr.apply_update()
     torch.cuda.synchronize()
     for a, b in zip(rob.nn_models.parameters(), params32):
-        assert rel_l2(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6
+        # the first Adam step moves every weight by ~lr = 1e-2 against values of ~1e-2: compare absolutely (same bar
+        # as test_cfg3_full_size_training_step)
+        assert float((a.detach() - b.detach()).abs().max()) < 1e-6
     assert float(rob.nn_models[0].weight.min()) >= 0 and float(rob.nn_models[2].weight.min()) >= 0
     # a second epoch runs on the updated weights and lowers or keeps the loss scale finite
     l2 = float(tr.step())

@@ -569,6 +569,8 @@ def test_estimate_state_on_device(torch_cuda, N):
     assert np.array_equal(np.asarray(r2.Kse_vstar, dtype=np.float64), kv)
     for rows in (slice(0, 7), slice(13, 19), slice(7, 13), slice(19, 25)):
         assert rel_l2(a2[:, rows], b2[:, rows]) < 1e-9
-        assert rel_l2(a2[:, rows], a[:120, rows]) < 1e-9  # same input rows, same Kse_vstar: same estimate
+        # same input rows, same Kse_vstar: same estimate (away from the end, where np.gradient's one-sided
+        # stencil sits at a different row)
+        assert rel_l2(a2[:100, rows], a[:100, rows]) < 1e-9
     with pytest.raises(Exception):
         kest.estimate_state(data[:, :, :-1], ctl, r2)
