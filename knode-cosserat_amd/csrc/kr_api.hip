@@ -30,6 +30,20 @@ int ensure_ws(kr_handle* h, size_t bytes) {
   return KR_OK;
 }
 
+int ensure_resume(kr_handle* h, int64_t B) {
+  const size_t bytes = (size_t)B * sizeof(int32_t);
+  if (bytes <= h->resume_cap) return KR_OK;
+  if (h->resume_buf) {
+    KR_HIP(hipDeviceSynchronize());
+    KR_HIP(hipFree(h->resume_buf));
+    h->resume_buf = nullptr;
+    h->resume_cap = 0;
+  }
+  KR_HIP(hipMalloc(&h->resume_buf, bytes + bytes / 4));
+  h->resume_cap = bytes + bytes / 4;
+  return KR_OK;
+}
+
 static void mat3_diag(double* m, double a, double b, double c) {
   for (int i = 0; i < 9; ++i) m[i] = 0;
   m[0] = a; m[4] = b; m[8] = c;
@@ -357,6 +371,7 @@ int kr_create(const kr_params* p, int device, kr_handle** out) {
   }
   if (const char* e = std::getenv("KR_PREDICTOR")) h->predictor = std::atoi(e);
   if (const char* e = std::getenv("KR_PERSISTENT")) h->persistent = std::atoi(e) ? 1 : 0;
+  if (const char* e = std::getenv("KR_OVERLAP")) h->overlap = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_MFMA_MLP")) h->mfma_mlp = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_FUSED_MLP")) h->fused_mlp = std::atoi(e) ? 1 : 0;
   *out = h;
@@ -390,6 +405,8 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
   } else if (n == "predictor") {
     if (value < 0 || value > 8) { set_error("predictor must be 0 .. 8"); return KR_E_ARG; }
     h->predictor = value;
+  } else if (n == "overlap") {
+    h->overlap = value ? 1 : 0;
   } else {
     set_error("unknown option " + n);
     return KR_E_ARG;
@@ -413,6 +430,8 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   else if (n == "last_sim_path") *value = h->last_sim_path;
   else if (n == "waves_per_rod") *value = h->waves_per_rod;
   else if (n == "last_waves_per_rod") *value = h->last_waves_per_rod;
+  else if (n == "overlap") *value = h->overlap;
+  else if (n == "last_overlap") *value = h->last_overlap;
   else {
     set_error("unknown option " + n);
     return KR_E_ARG;
@@ -431,6 +450,7 @@ int kr_destroy(kr_handle* h) {
   free_mlp(h);
   if (h->ws) (void)hipFree(h->ws);
   if (h->pred_buf) (void)hipFree(h->pred_buf);
+  if (h->resume_buf) (void)hipFree(h->resume_buf);
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   delete h;
   return KR_OK;

@@ -86,6 +86,10 @@ struct kr_handle {
   int fused_mlp = 1;         // training: fused MFMA forward/backward kernels (kr_mlp_fused.hip) when the shape allows
   int mfma_mlp = 1;          // evaluate the in-sweep MLP on the matrix cores when its shape allows
   int persistent = 1;        // kr_simulate_batch: run all steps in one launch when the multiple-shooting kernel applies
+  int overlap = 1;           // ... and overlap the verifying sweep of step t with the Jacobian sweep of step t + 1 (kr_mso_impl.hpp)
+  int last_overlap = 0;      // the last kr_simulate_batch ran the overlapped kernel
+  void* resume_buf = nullptr;  // int32 per rod (SimArgs::resume)
+  size_t resume_cap = 0;
 };
 
 namespace kr {
@@ -176,11 +180,20 @@ struct SimArgs {
   unsigned long long* dbg;  // diagnostic builds (-DKR_MS_STAMPS): [B][24] cycle counters, else unused
   double* pred_io;          // predictor image [B][KR_PRED_IMG_DOUBLES]: saved at the end (nullable)
   int pred_load;            // ... and loaded at the start instead of building the predictor from the states
+  // Two-launch form (kr_mso_impl.hpp): the overlapped kernel leaves, per rod, the first step it did NOT finish
+  // (T_steps: all done); the one-wavefront persistent kernel launched behind it with the same arguments resumes
+  // exactly there with its full fallback ladder.  nullptr: every rod starts at step 0.
+  int32_t* resume = nullptr;
 };
 
 // returns 1 when the persistent form does not apply
 template <typename T>
 int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>& a, hipStream_t s);
+// kr_mso_f32.hip / kr_mso_f64.hip: the overlapped persistent kernel (diagonal material matrices, Euler, MLP off);
+// returns 1 when it does not serve the problem
+template <typename T>
+int launch_mso_sim(kr_handle* h, const SimArgs<T>& a, hipStream_t s);
+int ensure_resume(kr_handle* h, int64_t B);
 
 // kr_mlp_fused.hip: fused fp32 MLP forward / backward for training
 bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad);

@@ -1370,8 +1370,13 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   // registers (regP), both indexed lane-per-grid-point: the BDF2 history of the next step never
   // touches HBM
   T regP[MS_NPL][12];
-  const T* s0 = A.states + rod * rod_elems;
-  const T* sp = A.prev_init ? A.prev_init + rod * rod_elems : s0;
+  // second launch of the two-launch form (kr_mso_impl.hpp): take over where the overlapped kernel stopped
+  const int64_t t0 = A.resume ? (int64_t)A.resume[rod] : 0;
+  if (t0 >= A.T_steps) return;
+  const bool resumed = t0 > 0;
+  const T* s0 = A.states + (A.ring ? t0 % 3 : t0) * A.slot_elems + rod * rod_elems;
+  const T* sp = resumed ? A.states + (A.ring ? (t0 - 1) % 3 : t0 - 1) * A.slot_elems + rod * rod_elems
+                        : (A.prev_init ? A.prev_init + rod * rod_elems : s0);
 #pragma unroll
   for (int q = 0; q < MS_NPL; ++q) {
     const int j = lane + q * WAVE;
@@ -1387,8 +1392,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   }
   MsPred<T> Q;
   double* img = A.pred_io ? A.pred_io + (size_t)rod * MS_PRED_ROWS * WAVE : nullptr;
-  if (img && A.pred_load) ms_pred_load<T>(Q, img, lane);
-  else ms_pred_init<T>(Q, lane, R, s0, sp, A.prev_init != nullptr, A.predictor);
+  if (img && A.pred_load && !resumed) ms_pred_load<T>(Q, img, lane);
+  else ms_pred_init<T>(Q, lane, R, s0, sp, resumed || A.prev_init != nullptr, A.predictor);
   MsSolveArgs<T> S;
   {
     const T* cl = s0 + (size_t)(N - 1) * KR_SLOTS;
@@ -1401,7 +1406,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) tens[k] = ctl[k];
+  for (int k = 0; k < 4; ++k) tens[k] = ctl[t0 * 4 + k];
   wave_sync();
 
   MsStamps stamps;
@@ -1415,7 +1420,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   // step, the shader-clock counter and the constant 100 MHz counter
   const bool clock_trace = A.dbg && rod == 0 && A.dbg[(A.B - 1) * 24 + 15] == 0xC10CULL;
 #endif
-  for (int64_t t = 0; t < A.T_steps; ++t) {
+  for (int64_t t = t0; t < A.T_steps; ++t) {
 #ifdef KR_MS_STAMPS
     KR_STAMP(tp);
     if (clock_trace && lane == 0) {
@@ -1605,6 +1610,21 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
   if (P.N - 1 < 2 * MS_P || P.N > MS_NPL * WAVE) return 1;
   if (ms_lds_bytes<T, hs_phys<T>()>(P.N, true) > (size_t)h->lds_limit) return 1;
   if (h->ms_mode != 1 && a.B > (int64_t)h->ms_batch_limit) return 1;
+  h->last_overlap = 0;
+  if (scheme == KR_EULER && P.diag && h->overlap) {
+    // two launches: the overlapped kernel (one sweep per step in the steady state), then this file's persistent
+    // kernel for the rods that left steps behind (a rod that finished exits at once)
+    SimArgs<T> a2 = a;
+    int rc = ensure_resume(h, a.B);
+    if (rc) return rc;
+    a2.resume = static_cast<int32_t*>(h->resume_buf);
+    rc = launch_mso_sim<T>(h, a2, s);
+    if (rc == KR_OK) {
+      h->last_overlap = 1;
+      return launch_ms_sim_inst<T, true, KR_EULER, false>(P, M, a2, s);
+    }
+    if (rc != 1) return rc;
+  }
   if (scheme == KR_EULER) {
     if constexpr (sizeof(T) == 4) {
       // fp32, more rods than SIMDs, and two workgroups fit the LDS of a CU: the two-wavefronts-per-SIMD instantiation
@@ -1622,6 +1642,7 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
 
 #include "kr_msw_impl.hpp"  // several wavefronts per rod (uses everything above)
 
+#ifndef KR_MS_NO_INST  // (kr_mso_*.hip include this file for its device functions only)
 namespace kr {
 template int launch_sim_persistent<KR_SIM_T>(kr_handle*, int, int, const SimArgs<KR_SIM_T>&, hipStream_t);
 template int step_waves_per_rod<KR_SIM_T>(kr_handle*, int, int, int64_t, int);
@@ -1629,3 +1650,4 @@ template int step_waves_per_rod<KR_SIM_T>(kr_handle*, int, int, int64_t, int);
 KR_INST(KR_SIM_T)
 
 }  // namespace kr
+#endif

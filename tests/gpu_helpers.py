@@ -9,8 +9,11 @@ another mode) and ``assert_path`` after the simulation (the handle reports what 
 import numpy as np
 import pytest
 
-MODES = ["single", "multi", "persistent"]
-PATH_OF_MODE = {"single": 0, "multi": 1, "persistent": 2}
+MODES = ["single", "multi", "persistent", "overlap"]
+# "overlap": the persistent launch with the verifying sweep of step t folded into the Jacobian sweep of step t + 1
+# (kr_mso_impl.hpp, the default where it applies); "persistent" pins the plain persistent kernel (KR_OVERLAP=0).
+# Pseudo path 3 = path 2 with the overlapped kernel.
+PATH_OF_MODE = {"single": 0, "multi": 1, "persistent": 2, "overlap": 3}
 MS_P = 4            # sub-intervals of the multiple-shooting kernels (kr_ms_impl.hpp)
 PERSIST_MAX_N = 128  # the persistent kernel keeps the older history lane-per-grid-point in registers
 
@@ -19,7 +22,8 @@ def set_mode_env(monkeypatch, mode, waves_per_rod=1):
     """kr_create reads KR_MS_MODE / KR_PERSISTENT / KR_WAVES_PER_ROD.  The modes pin one wavefront per rod; the
     several-wavefront form of path 1 (kr_msw_impl.hpp) has its own tests (test_gpu_msw.py)."""
     monkeypatch.setenv("KR_MS_MODE", "0" if mode == "single" else "1")
-    monkeypatch.setenv("KR_PERSISTENT", "1" if mode == "persistent" else "0")
+    monkeypatch.setenv("KR_PERSISTENT", "1" if mode in ("persistent", "overlap") else "0")
+    monkeypatch.setenv("KR_OVERLAP", "1" if mode == "overlap" else "0")
     monkeypatch.setenv("KR_WAVES_PER_ROD", str(waves_per_rod))
 
 
@@ -75,6 +79,8 @@ def expected_path(mode, N, mlp=None, scheme="euler"):
         return 1
     if N > PERSIST_MAX_N or (mlp is not None and scheme != "euler"):
         return 1
+    if mode == "overlap":  # Euler sweeps, MLP off, diagonal material matrices (every preset)
+        return 3 if (mlp is None and scheme == "euler") else 2
     return 2
 
 
@@ -89,6 +95,8 @@ def require_path(mode, N, mlp=None, scheme="euler"):
 def assert_path(robot_or_handle, want, waves_per_rod=1):
     h = robot_or_handle if hasattr(robot_or_handle, "get_option") else robot_or_handle._handle
     got = h.get_option("last_sim_path")
+    if got == 2 and h.get_option("last_overlap"):
+        got = 3
     assert got == want, f"kernel path {got} ran, the test is meant to exercise path {want}"
     if want == 1:
         w = h.get_option("last_waves_per_rod")
