@@ -31,12 +31,21 @@
 namespace kr {
 
 constexpr int MSO_B0 = 7 + 17 * (MS_P - 1);  // 58: first of the four lanes that re-integrate the step under verification
-constexpr int MSO_LAG = 2;  // grid points the verifying lanes run ahead (>= 2: records are prefetched a trip early)
+constexpr int MSO_LAG = 2;  // grid points the verifying lanes run ahead of the lanes that consume their records (1 measures the same)
 static_assert(MSO_B0 + MS_P <= WAVE, "the verifying lanes must fit beside the forward-difference lanes");
 
 template <typename T, int HS>
 __host__ __device__ inline size_t mso_lds_elems(int N) {
   return ms_lds_elems<T, HS>(N, true, false) + 80;  // + XsB: the unknowns of the step under verification
+}
+
+// Hand-offs between lanes of ONE wavefront through LDS need no hardware wait: the LDS unit serves a wavefront's
+// accesses in order, and the compiler tracks the counters of the loads it consumes.  What is needed is that the
+// compiler does not move LDS accesses across the hand-off - a wavefront-scope fence.  (wave_sync()'s workgroup-scope
+// fence also waits for every outstanding global store, i.e. for the records a sweep has just streamed out.)
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 #ifdef KR_MS_STAMPS
@@ -148,7 +157,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
   const int pi = plane ? lane / 3 : 0;  // term i = 0 .. P-2
   const int prow = plane ? lane - 3 * pi : 0;
   const bool glane = lane >= WAVE - 6;  // six lanes own the base wrench in the update step
+  // (tensions are requested one step before they are needed: a load from HBM takes longer than what lies between
+  // the hand-over of a step and the sweep that follows)
   V3<T> fcA = load_fc(0), fcB = fcA;
+  V3<T> fcN = load_fc(T_steps > 1 ? 1 : 0);
   // av = hk_a + hk_b v_h, au = hk_c u_h (diagonal material matrices): kept in registers so that forming a history
   // record inside a sweep does not go back to the parameter table
   static_assert(DIAG, "the in-sweep history record assumes diagonal material matrices");
@@ -161,9 +173,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
   }
 
   ms_pred_guess<T>(Q, order, lane, L.cold, Xs);
-  wave_sync();
+  wave_sync_lds();
   if (order <= 0 && lane < 6) Xs[0 * MS_YP + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
-  wave_sync();
+  wave_sync_lds();
 
   // p rows, scaled update norm and the per-lane pieces of an update of the unknowns X from base end states Eb(g)
   // (A: Es slot of the interval's unperturbed lane; B: EsB) - the tail both the chord and the Newton update share.
@@ -234,7 +246,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
         }
       }
       // history record of the next trip.  A forward-difference lane reads what a verifying lane wrote
-      // MSO_LAG - 1 >= 1 trips ago; a verifying lane reads a record it has not replaced yet.
+      // MSO_LAG - 1 trips ago (for MSO_LAG = 1: above, in this trip); a verifying lane reads a record it has not
+      // replaced yet.
       load_hist_vec<T, HS>(L.hist + (size_t)point_of(k + 1) * HS, hv);
       const T dsl = live ? Pc.ds : T(0);  // (a lane outside its range evaluates finite data and adds nothing)
       y = state_axpy(y, dsl, k1);
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
 #pragma unroll
         for (int g = 1; g < MS_P - 1; ++g) dYb[g * MS_YP + r] = updY[g - 1];
       }
-      wave_sync();
+      wave_sync_lds();
       if (plane) {
         const int l0 = pi == 0 ? 0 : 7 + 17 * (pi - 1);
         T s = Es[base_slot(pi) * MS_YP + prow] - X[(pi + 1) * MS_YP + prow];
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
         }
         sp[pi * 3 + prow] = s + s2;
       }
-      wave_sync();
+      wave_sync_lds();
       float nf = 0.f;
       U.updP = T(0); U.updG = T(0); U.xsP = T(0); U.xsG = T(0);
       if (plane) {  // this lane owns Y_{pi+1}[prow]
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
           }
         }
       }
-      wave_sync();
+      wave_sync_lds();
       // residual of the sweep: interface jumps E_g - Y_{g+1} and the tip condition, one component per lane
       float rn = 0.f;
       if (lane < 3 * MS_YP) {
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
         T areg[MS_P - 1];
         areg[0] = EsB[0 * MS_YP + r] - XsB[1 * MS_YP + r];  // a_1 = c_0
         if (kp == 0) ach[1 * MS_YP + r] = areg[0];
-        wave_sync();
+        wave_sync_lds();
 #pragma unroll
         for (int g = 1; g < MS_P; ++g) {
           const int l0 = 7 + 17 * (g - 1);
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
           } else if (kp == 0 && r >= 7 && r < 13) {
             rt[r - 7] = L.cold[CD_FTIP + (r - 7)] - e0 - part;
           }
-          wave_sync();
+          wave_sync_lds();
         }
         {
           T rtv[6];
@@ -443,9 +456,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
 #endif
         const bool ok = dnv <= 3.0e38f;
         if (ok) apply(XsB);
-        wave_sync();
+        wave_sync_lds();
         for (int e = lane; e < MS_NE; e += WAVE) Xs[e] = XsB[e];
         tA = tB;
+        fcN = fcA;
         fcA = fcB;
         order = orderB;
         it = itB;
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
 #pragma unroll
         for (int q = 0; q < 19; ++q) Es[lane * MS_YP + q] = er[q];
       }
-      wave_sync();
+      wave_sync_lds();
       res_full = ms_residual_norm<T>(Es, Xs, L.cold, lane);
       if (isA && col > 0) {
         const T ih = fast_rcp(hstep);
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
 #pragma unroll
         for (int q = 0; q < 19; ++q) Es[lane * MS_YP + q] = (er[q] - e0[q]) * ih;
       }
-      wave_sync();
+      wave_sync_lds();
     }
     dYb = XB;
     {
@@ -499,7 +513,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
       Xreg[0][1] = kp == 3 ? T(0) : db;
       store_pair(XB + r * 8 + 2 * kp, Xreg[0][0], Xreg[0][1]);
     }
-    wave_sync();
+    wave_sync_lds();
 #pragma unroll
     for (int g = 1; g < MS_P; ++g) {
       const T* xcur = XB + ((g - 1) & 1) * (MS_YP * 8);
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
         if (kp == 0) n0 = L.cold[CD_FTIP + (r - 7)] - e0 - n0;  // F_tip (3) and M_tip (3) are adjacent
         store_pair(Tm + (r - 7) * 8 + 2 * kp, n0, n1);
       }
-      wave_sync();
+      wave_sync_lds();
     }
     {
       T a6[6][7];
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
       next_final = predict_final<T>(dn, dn_prev, tol, tolA) || (kappa > T(0) && T(4) * kappa * dn * dn <= tol);
       dn_prev = dn;
     }
-    wave_sync();
+    wave_sync_lds();
 #ifdef KR_MS_STAMPS
     KR_STAMP_ADD(st.t_alg, tq);
 #endif
@@ -601,9 +615,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
         retried = true;
         order = 0;
         ms_pred_guess<T>(Q, 0, lane, L.cold, Xs);
-        wave_sync();
+        wave_sync_lds();
         if (lane < 6) Xs[0 * MS_YP + 7 + lane] = Gguess;
-        wave_sync();
+        wave_sync_lds();
         it = 0; dn_prev = T(-1); have_fac = false; amp = -1.f; below = false;
 #ifdef KR_MS_STAMPS
         st.retries += 1;
@@ -616,18 +630,19 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
     if (next_final && dn <= T(1e-2)) {
       // hand step tA to the verifying lanes and move the forward-difference lanes on to step tA + 1
       for (int e = lane; e < MS_NE; e += WAVE) XsB[e] = Xs[e];
-      wave_sync();
+      wave_sync_lds();
       dnB = dn; ampB = amp; belowB = below; itB = it; orderB = order;
       if (!pred_skip) ms_pred_update<T>(Q, order, KR_ST_CONVERGED, A.predictor, lane, XsB, stamps);
       tA += 1;
       fcB = fcA;
       if (tA < T_steps) {
-        fcA = load_fc(tA);
+        fcA = fcN;
+        fcN = load_fc(tA + 1 < T_steps ? tA + 1 : tA);
         order = Q.next_order;
         ms_pred_guess<T>(Q, order, lane, L.cold, Xs);
-        wave_sync();
+        wave_sync_lds();
         if (order <= 0 && lane < 6) Xs[0 * MS_YP + 7 + lane] = XsB[0 * MS_YP + 7 + lane];  // warm start: the G just found
-        wave_sync();
+        wave_sync_lds();
       }
       it = 0; retried = false; below = false; dn_prev = T(-1);
       merged = true;
