@@ -846,6 +846,143 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 }
 
 // ---- one time step per launch: one workgroup of W wavefronts per rod -----------------------------------------
+// ---------------------------------------------------------------------------
+// Last resort of a time step, as in kr_ms_impl.hpp (ss_newton_damped): damped single shooting on wavefront 0 - Newton
+// on the 6 base unknowns with a forward-difference Jacobian from lanes 1..6, every update taken as G - lam d with lam
+// halved until the residual norm has decreased, iteration cap 8 x maxit (the oracle's newton_shoot(damped=True)).
+// Lane 0 streams every sweep; the sweep whose full Newton update is below the tolerance is the accepted one.  Leaves
+// L.Xs (all P interval starts) consistent with the result, so the predictor of every wavefront sees the accepted
+// unknowns.  Called by wavefront 0 only; the other wavefronts wait at the workgroup barrier that follows.  With it the
+// status of a hard step no longer depends on which kernel the batch size selects.
+// ---------------------------------------------------------------------------
+template <typename T, bool DIAG, int W>
+__device__ __forceinline__ int msw_ss_damped(const RodConst<T>& Pc, const MswLds<T, W>& L, int lane, V3<T> fconst,
+                                             MsSolveArgs<T>& S, int& it) {
+  constexpr int P = MswGeo<W>::P;
+  const int N = Pc.N;
+  const int col = lane < 7 ? lane : 0;  // lanes 7.. duplicate the unperturbed column and store nothing
+  T G[6], Gold[6], d[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { G[k] = L.Xs[0 * 19 + 7 + k]; Gold[k] = G[k]; d[k] = T(0); }
+  T nr_old = T(-1), lam = T(1);
+  bool have_trial = false;
+  int status = KR_ST_MAXIT;
+  const int maxit = 8 * S.maxit;
+  it = 0;
+  T* Rx = L.Es;  // [7][6] residuals of the seven columns (Es of wavefront 0 is free between sweeps)
+  while (true) {
+    T hs[6];
+    RodState<T> y;
+    {
+      const T* cold = L.cold;
+      y.p = {cold[CD_P0], cold[CD_P0 + 1], cold[CD_P0 + 2]};
+      y.h0 = cold[CD_H0]; y.h1 = cold[CD_H0 + 1]; y.h2 = cold[CD_H0 + 2]; y.h3 = cold[CD_H0 + 3];
+      y.q = {cold[CD_Q0], cold[CD_Q0 + 1], cold[CD_Q0 + 2]};
+      y.w = {cold[CD_W0], cold[CD_W0 + 1], cold[CD_W0 + 2]};
+      T Gl[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        hs[k] = S.fd_eps * fmax(fabs(G[k]), T(1));
+        Gl[k] = G[k] + (col == k + 1 ? hs[k] : T(0));
+      }
+      y.n = {Gl[0], Gl[1], Gl[2]};
+      y.m = {Gl[3], Gl[4], Gl[5]};
+    }
+    int gnext = 1, jnext = msw_start(1, N, P);  // interval starts passed on the way (for L.Xs)
+    for (int j = 0; j < N - 1; ++j) {
+      T hv[HS_LEAN];
+      load_hist_vec<T, HS_LEAN>(L.hist + (size_t)j * HS_LEAN, hv);
+      RodState<T> k1;
+      V3<T> v, u;
+      ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
+      if (lane == 0) {
+        T rec[KR_SLOTS];
+        record_from(y, v, u, rec);
+        if (S.out_rod) store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
+        if (S.lead12) {
+          T lead[12];
+#pragma unroll
+          for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+          store_vec<T, 12>(S.lead12 + (size_t)j * 12, lead);
+        }
+        if (j == jnext && gnext < P) {
+          T yr[19];
+          state_to_rows(y, yr);
+#pragma unroll
+          for (int q = 0; q < 19; ++q) L.Xs[gnext * 19 + q] = yr[q];
+        }
+      }
+      if (j == jnext && gnext < P) { ++gnext; jnext = msw_start(gnext, N, P); }
+      y = state_axpy(y, Pc.ds, k1);
+    }
+    if (lane == 0) {
+      T rec[KR_SLOTS];
+      record_from(y, S.vlast, S.ulast, rec);
+      if (S.out_rod) store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+      if (S.lead12) {
+        T lead[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+        store_vec<T, 12>(S.lead12 + (size_t)(N - 1) * 12, lead);
+      }
+      if (S.tip) { S.tip[0] = y.p.x; S.tip[1] = y.p.y; S.tip[2] = y.p.z; }
+    }
+    ++it;
+    if (lane < 7) {
+      Rx[lane * 6 + 0] = L.cold[CD_FTIP + 0] - y.n.x; Rx[lane * 6 + 1] = L.cold[CD_FTIP + 1] - y.n.y;
+      Rx[lane * 6 + 2] = L.cold[CD_FTIP + 2] - y.n.z; Rx[lane * 6 + 3] = L.cold[CD_MTIP + 0] - y.m.x;
+      Rx[lane * 6 + 4] = L.cold[CD_MTIP + 1] - y.m.y; Rx[lane * 6 + 5] = L.cold[CD_MTIP + 2] - y.m.z;
+    }
+    wave_sync();
+    T a[6][7];
+    T nr = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      a[k][6] = Rx[k];
+      nr = fma(a[k][6], a[k][6], nr);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const T ih = fast_rcp(hs[c]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a[k][c] = (Rx[(c + 1) * 6 + k] - a[k][6]) * ih;
+    }
+    wave_sync();
+    // backtracking (nr is a squared norm; a NaN fails the comparison and counts as "not decreased")
+    const T keep = T(1) - T(1e-4) * lam;
+    if (have_trial && !(nr <= nr_old * keep * keep) && lam > T(1.0 / 1024.0) && it < maxit) {
+      lam *= T(0.5);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) G[k] = Gold[k] - lam * d[k];
+      continue;
+    }
+    T dn[6];
+    solve6(a, dn);
+    T dmax = T(0), gmax = T(1);
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      dmax = fmax(dmax, fabs(dn[k]));
+      gmax = fmax(gmax, fabs(G[k]));
+      finite = finite && isfinite(dn[k]);
+    }
+    if (!finite) { status = KR_ST_NONFINITE; break; }
+    if (dmax <= S.tol * gmax) { status = KR_ST_CONVERGED; break; }  // this sweep's state is the accepted one
+    if (it >= maxit) break;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { Gold[k] = G[k]; d[k] = dn[k]; G[k] = G[k] - dn[k]; }
+    nr_old = nr;
+    lam = T(1);
+    have_trial = true;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.Xs[0 * 19 + 7 + k] = G[k];
+  }
+  wave_sync();
+  return status;
+}
+
 template <typename T, bool DIAG, int W>
 __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc, const StepArgs<T> A) {
   constexpr int P = MswGeo<W>::P;
@@ -921,6 +1058,19 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
     }
+    if (status != KR_ST_CONVERGED) {  // (uniform over the workgroup) plain Newton failed from the warm start too
+      __syncthreads();
+      if (wave == 0) {
+        if (lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];
+        wave_sync();
+        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it);
+        if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
+      }
+      __syncthreads();
+      status = (int)L.red[0];
+      it = (int)L.red[1];
+      __syncthreads();
+    }
 #ifdef KR_MS_STAMPS
     KR_STAMP(tp);
 #endif
@@ -945,6 +1095,19 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
     }
     __syncthreads();
     status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
+    if (status != KR_ST_CONVERGED) {  // damped single shooting from the caller's guess
+      __syncthreads();
+      if (wave == 0) {
+        if (lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];
+        wave_sync();
+        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it);
+        if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
+      }
+      __syncthreads();
+      status = (int)L.red[0];
+      it = (int)L.red[1];
+      __syncthreads();
+    }
   }
   if (wave == 0 && lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * 19 + 7 + lane];
   if (wave == 0 && lane == 0) {
@@ -1060,6 +1223,19 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
       status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
+      __syncthreads();
+    }
+    if (status != KR_ST_CONVERGED) {  // (uniform over the workgroup) plain Newton failed from the warm start too
+      __syncthreads();
+      if (wave == 0) {
+        if (lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;
+        wave_sync();
+        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it);
+        if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
+      }
+      __syncthreads();
+      status = (int)L.red[0];
+      it = (int)L.red[1];
       __syncthreads();
     }
     if (wave == 0 && lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
