@@ -288,6 +288,19 @@ int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const flo
 int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                  const float* lower, double lr, double beta1, double beta2, double eps, double weight_decay,
                  int64_t step, int64_t n_zero, void* stream);
+/* kr_adam_step with the learning rate and torch.optim.lr_scheduler.ReduceLROnPlateau(mode "min", relative
+ * threshold, cooldown 0) kept on the DEVICE - physics_train.py:206 creates the scheduler, :296-297 call
+ * optimizer.step(); scheduler.step(total_loss) every epoch - so that an epoch needs no host round trip.
+ * sched: 6 doubles in device memory, initialised by the caller to {lr, lr, +inf, 0, 0, 0}: [0]/[1] learning rate
+ * of odd / even steps (step s uses sched[(s-1)&1], the rate of step s+1 goes to sched[s&1]), [2] best loss,
+ * [3] bad epochs in a row, [4] loss of the step just taken, [5] reductions so far.  The loss is read from
+ * grads[loss_index] (the trailing slot of the flat buffer, already all-reduced) before that slot is zeroed;
+ * loss_log (nullable, device) receives it as a float.  Note: the fp32 step size is formed as lr * (1 / bias
+ * correction) on the device; kr_adam_step forms lr / bias correction on the host - the same to rounding. */
+int kr_adam_plateau_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                         const float* lower, double* sched, double beta1, double beta2, double eps,
+                         double weight_decay, int64_t step, int64_t n_zero, int64_t loss_index, double factor,
+                         int patience, double threshold, double min_lr, float* loss_log, void* stream);
 
 /* The same loss against pre-gathered targets: the states a training set is scored against never
  * change between epochs, so kr_gather_targets extracts rows[S*K][25] once (y rows at column idx[k],

@@ -341,6 +341,53 @@ __global__ void adam_kernel(int64_t n, int64_t n_zero, float* __restrict__ p, fl
     g[i] = 0.f;
   }
 }
+// Adam + clamp + gradient zeroing as above, with the learning rate and torch's ReduceLROnPlateau(mode="min",
+// threshold_mode="rel", cooldown=0) kept ON THE DEVICE, so that an epoch needs no host round trip
+// (physics_train.py:206,296-297 call scheduler.step(total_loss) after every optimizer.step()).
+// sched[0], sched[1]: learning rate of odd / even steps (step s reads sched[(s - 1) & 1] and writes the rate of step
+// s + 1 to sched[s & 1]: no thread of this launch reads what another one writes), sched[2] best loss so far,
+// sched[3] bad epochs in a row, sched[4] loss of this step, sched[5] number of reductions.
+// The thread that owns the loss slot of the gradient buffer (index loss_idx) is the scheduler: it reads the loss
+// before zeroing it.
+__global__ void adam_plateau_kernel(int64_t n, int64_t n_zero, float* __restrict__ p, float* __restrict__ g,
+                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ lower,
+                                    double* __restrict__ sched, int parity, float inv_bc1, float b1, float b2,
+                                    float inv_sqrt_bc2, float eps, float wd, int64_t loss_idx, double factor,
+                                    int patience, double threshold, double min_lr, float* __restrict__ loss_log) {
+  const double lr = sched[parity];
+  const float step_size = (float)(lr * (double)inv_bc1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n) {
+      float pi = p[i];
+      float gi = g[i];
+      if (wd != 0.f) gi = fmaf(wd, pi, gi);
+      const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+      const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+      m[i] = mi;
+      v[i] = vi;
+      const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+      pi -= step_size * (mi / denom);
+      if (lower) pi = fmaxf(pi, lower[i]);
+      p[i] = pi;
+    }
+    if (i == loss_idx) {
+      const double cur = (double)g[i];
+      double best = sched[2], bad = sched[3], red = sched[5];
+      if (cur < best * (1.0 - threshold)) { best = cur; bad = 0.0; }  // (torch: best starts at +inf; a NaN loss is "not better")
+      else bad += 1.0;
+      double next = lr;
+      if (bad > (double)patience) {
+        const double cand = fmax(lr * factor, min_lr);
+        if (lr - cand > 1e-8) { next = cand; red += 1.0; }  // ReduceLROnPlateau's eps
+        bad = 0.0;
+      }
+      sched[parity ^ 1] = next;
+      sched[2] = best; sched[3] = bad; sched[4] = cur; sched[5] = red;
+      if (loss_log) *loss_log = (float)cur;
+    }
+    g[i] = 0.f;
+  }
+}
 }  // namespace kr
 
 using namespace kr;
@@ -635,6 +682,27 @@ int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* ex
   hipLaunchKernelGGL(kr::adam_kernel, dim3(grid), dim3(256), 0, s, n, n_zero, params, grads, exp_avg, exp_avg_sq, lower,
                      (float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 / std::sqrt(bc2)), (float)eps,
                      (float)weight_decay);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+int kr_adam_plateau_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                         const float* lower, double* sched, double beta1, double beta2, double eps,
+                         double weight_decay, int64_t step, int64_t n_zero, int64_t loss_index, double factor,
+                         int patience, double threshold, double min_lr, float* loss_log, void* stream) {
+  KR_CHECK_H(h);
+  if (n < 0 || n_zero < n || step < 1) { set_error("kr_adam_plateau_step: need n >= 0, n_zero >= n, step >= 1"); return KR_E_ARG; }
+  if (loss_index < 0 || loss_index >= n_zero) { set_error("kr_adam_plateau_step: loss_index must lie in [0, n_zero)"); return KR_E_ARG; }
+  if (!(factor > 0.0 && factor < 1.0) || patience < 0) { set_error("kr_adam_plateau_step: need 0 < factor < 1, patience >= 0"); return KR_E_ARG; }
+  KR_CHECK_PTR(grads); KR_CHECK_PTR(sched);
+  if (n) { KR_CHECK_PTR(params); KR_CHECK_PTR(exp_avg); KR_CHECK_PTR(exp_avg_sq); }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+  int grid = (int)((n_zero + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(kr::adam_plateau_kernel, dim3(grid), dim3(256), 0, s, n, n_zero, params, grads, exp_avg, exp_avg_sq,
+                     lower, sched, (int)((step - 1) & 1), (float)(1.0 / bc1), (float)beta1, (float)beta2,
+                     (float)(1.0 / std::sqrt(bc2)), (float)eps, (float)weight_decay, loss_index, factor, patience,
+                     threshold, min_lr, loss_log);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }

@@ -60,6 +60,38 @@ class FlatBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
 
+class DevicePlateau:
+    """``torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'min', patience, factor)`` whose state lives in device
+    memory and is advanced by ``kr_adam_plateau_step`` inside the optimizer launch (physics_train.py:206,297).  The
+    methods the training drivers use are kept: ``get_last_lr()`` (a device read: call it when printing, not every
+    epoch), ``state_dict()`` / ``load_state_dict()``."""
+
+    def __init__(self, lr, patience, factor, device, threshold=1e-4, min_lr=0.0):
+        self.patience, self.factor, self.threshold, self.min_lr = int(patience), float(factor), float(threshold), float(min_lr)
+        self.buf = torch.tensor([lr, lr, float("inf"), 0.0, 0.0, 0.0], dtype=torch.float64, device=device)
+        self.steps = 0
+
+    def _lr_index(self):
+        return self.steps & 1  # the rate the NEXT step will use (= what torch reports after scheduler.step())
+
+    def get_last_lr(self):
+        return [float(self.buf[self._lr_index()].item())]
+
+    def set_lr(self, lr):
+        self.buf[0:2] = float(lr)
+
+    def state_dict(self):
+        b = self.buf.cpu().tolist()
+        return {"lr": b[self._lr_index()], "best": b[2], "num_bad_epochs": int(b[3]), "last_loss": b[4],
+                "reductions": int(b[5]), "patience": self.patience, "factor": self.factor, "threshold": self.threshold,
+                "min_lr": self.min_lr}
+
+    def load_state_dict(self, sd):
+        self.buf[0:2] = float(sd["lr"])
+        self.buf[2] = float(sd.get("best", float("inf")))
+        self.buf[3] = float(sd.get("num_bad_epochs", 0))
+
+
 class KnodeTrainer:
     """One-step-ahead KNODE training on a fixed set of trajectories.
 
@@ -72,9 +104,12 @@ class KnodeTrainer:
     """
 
     def __init__(self, robot, trajs, controls, key_pt_idx, lr=1e-2, weight_decay=0.0, clamp_weights=True,
-                 patience=80, factor=0.5, group=None, keep_pred=False, native_adam=True):
+                 patience=80, factor=0.5, group=None, keep_pred=False, native_adam=True, device_plateau=None):
         self.robot = robot
         self.native_adam = native_adam  # Adam + clamp + gradient zeroing as ONE kernel (kr_adam_step)
+        # learning-rate schedule (ReduceLROnPlateau) advanced on the device inside the optimizer launch: an epoch
+        # then needs no host round trip at all (step(sync_loss=False)); default with the fused optimizer
+        self.device_plateau = native_adam if device_plateau is None else (bool(device_plateau) and native_adam)
         # keep_pred: write the predictions of every epoch (two kernels: forward, loss); otherwise the loss runs in the
         # epilogue of the forward kernel and predictions() evaluates them on demand
         self.keep_pred = keep_pred
@@ -162,8 +197,12 @@ class KnodeTrainer:
             # the option lives on the robot's (shared) handle: an earlier native-Adam trainer may have left it on,
             # and this branch relies on the library zeroing dW / db / loss itself
             h.set_option("mlp_grad_accumulate", 0)
-        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", patience=patience,
-                                                                    factor=factor)
+        if self.device_plateau:
+            self.scheduler = DevicePlateau(lr, patience, factor, dev)
+            self.loss_log = torch.zeros(4096, dtype=torch.float32, device=dev)  # loss of every epoch (grown on demand)
+        else:
+            self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", patience=patience,
+                                                                        factor=factor)
 
     def _ptr_arrays(self):
         n = self.n
@@ -197,7 +236,22 @@ class KnodeTrainer:
 
     def apply_update(self):
         """Adam + clamp on the gradients loss_and_grads() left in the bucket (physics_train.py:289-304)."""
-        if self.native_adam:
+        if self.native_adam and self.device_plateau:
+            h = self.h
+            self.adam_step += 1
+            n = self.flat_p.numel()
+            e = self.scheduler.steps
+            if e >= self.loss_log.numel():
+                self.loss_log = torch.cat([self.loss_log, torch.zeros_like(self.loss_log)])
+            sc = self.scheduler
+            kn.check(h.lib.kr_adam_plateau_step(
+                h._h, n, kn._ptr(self.flat_p), kn._ptr(self.bucket.flat), kn._ptr(self.exp_avg), kn._ptr(self.exp_avg_sq),
+                kn._ptr(self.lower) if self.clamp_weights else None, kn._ptr(sc.buf), self.betas[0], self.betas[1],
+                self.adam_eps, self.weight_decay, self.adam_step, n + 1, n, sc.factor, sc.patience, sc.threshold,
+                sc.min_lr, self.loss_log.data_ptr() + 4 * e, kn._stream()))
+            # the kernel reads sched[(adam_step - 1) & 1]; keep the scheduler's parity in step with Adam's
+            sc.steps = self.adam_step
+        elif self.native_adam:
             h = self.h
             self.adam_step += 1
             n = self.flat_p.numel()
@@ -213,16 +267,25 @@ class KnodeTrainer:
                         self.params[2 * k].clamp_(min=0)
 
     def step(self, sync_loss=True):
-        """One epoch of physics_train.py: returns the loss (float if sync_loss)."""
+        """One epoch of physics_train.py (:313-401): forward, loss, backward, all-reduce, Adam, plateau schedule, clamp.
+        With the device-side schedule nothing in here waits for the GPU unless ``sync_loss`` asks for the loss as a
+        float (``losses()`` returns the whole history later); otherwise the schedule is torch's and needs the value."""
         loss = self.loss_and_grads()
-        if sync_loss:
-            val = float(loss.item())  # before the update: the native Adam kernel also clears the loss slot
-        else:
-            val = loss.clone() if self.native_adam else loss
+        if self.device_plateau:
+            self.apply_update()  # (reads the loss slot on the device, logs it, steps the schedule, clears the slot)
+            if sync_loss:
+                return float(self.loss_log[self.scheduler.steps - 1].item())
+            return None
+        val = float(loss.item())  # before the update: the native Adam kernel also clears the loss slot
         self.apply_update()
-        if sync_loss:
-            self.scheduler.step(val)
+        self.scheduler.step(val)
         return val
+
+    def losses(self):
+        """Loss of every epoch taken so far (one device read)."""
+        if not self.device_plateau:
+            raise kn.KrError("losses(): only kept with the device-side schedule")
+        return self.loss_log[: self.scheduler.steps].cpu().tolist()
 
     def optimizer_state_dict(self):
         """``torch.optim.Adam.state_dict()`` layout (what physics_train.py:284-288 stores under 'optim'): per
@@ -237,7 +300,8 @@ class KnodeTrainer:
                             "exp_avg": self.exp_avg[off:off + sz].view(p.shape).clone(),
                             "exp_avg_sq": self.exp_avg_sq[off:off + sz].view(p.shape).clone()}
             off += sz
-        group = {"lr": float(self.optimizer.param_groups[0]["lr"]), "betas": tuple(self.betas), "eps": self.adam_eps,
+        lr_now = self.scheduler.get_last_lr()[0] if self.device_plateau else float(self.optimizer.param_groups[0]["lr"])
+        group = {"lr": lr_now, "betas": tuple(self.betas), "eps": self.adam_eps,
                  "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
                  "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
                  "params": list(range(len(self.params)))}
@@ -256,6 +320,8 @@ class KnodeTrainer:
         self.betas, self.adam_eps = tuple(group["betas"]), float(group["eps"])
         self.weight_decay = float(group["weight_decay"])
         self.optimizer.param_groups[0]["lr"] = float(group["lr"])
+        if self.device_plateau:
+            self.scheduler.set_lr(float(group["lr"]))
         steps, off = set(), 0
         for k, (p, sz) in enumerate(zip(self.params, self.bucket.sizes)):
             st = sd["state"].get(group["params"][k])
@@ -273,6 +339,10 @@ class KnodeTrainer:
         if len(steps) != 1:
             raise kn.KrError("per-parameter step counts differ: not a state the fused Adam can continue")
         self.adam_step = steps.pop()
+        if self.device_plateau:
+            self.scheduler.steps = self.adam_step  # (parity of the rate slot; the loss log restarts at this index)
+            if self.adam_step >= self.loss_log.numel():
+                self.loss_log = torch.zeros(2 * self.adam_step + 4096, dtype=torch.float32, device=self.loss_log.device)
 
     def predictions(self):
         """[S, 25, K] predictions with the current weights (reference layout of grow_trajs)."""

@@ -133,10 +133,15 @@ def main(argv=None):
 
     loss_arr, dtw_arr = [], []
     best = (float("inf"), None)
+    first_epoch = trainer.scheduler.steps if trainer.device_plateau else 0  # (> 0 after --resume)
     for epoch in range(args.epochs):
-        loss = trainer.step()
-        loss_arr.append(loss)
-        if epoch % 10 == 0:
+        # no host round trip inside an epoch: loss, Adam, plateau schedule and clamp all advance on the device; the
+        # loss is read back where the reference prints it (every 10 epochs, physics_train.py:270-272) and at the end
+        printing = epoch % 10 == 0
+        loss = trainer.step(sync_loss=printing or not trainer.device_plateau)
+        if not trainer.device_plateau:
+            loss_arr.append(loss)
+        if printing:
             say(f"Epoch {epoch} of {args.epochs}")
             say(f"Total loss: {loss}, lr {trainer.scheduler.get_last_lr()}")
         if epoch % 50 == 0 and args.eval and rank == 0:
@@ -146,6 +151,8 @@ def main(argv=None):
             say("Validation DTW Distance XYZ", dtw)
             if dtw < best[0]:
                 best = (dtw, {k: v.detach().clone() for k, v in robot.nn_models.state_dict().items()})
+    if trainer.device_plateau:
+        loss_arr = trainer.losses()[first_epoch:]
     if rank == 0:
         os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
         if best[1] is not None:

@@ -166,6 +166,45 @@ def test_native_adam_matches_torch(torch_cuda):
             assert rel_l2(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()) < 1e-4
 
 
+def test_device_plateau_schedule_matches_torch(torch_cuda):
+    """kr_adam_plateau_step: Adam + clamp + ReduceLROnPlateau with the learning rate kept on the device (no host round
+    trip per epoch) against the torch pair physics_train.py:199,206 builds - same loss curve, the same learning rate
+    after every epoch (a short patience and a large rate make the schedule bite several times), same weights."""
+    torch = torch_cuda
+    from krod_train import KnodeTrainer
+    g = load_golden("train_step")
+    traj = torch.tensor(g["traj"], device=DEV)[None]
+    controls = torch.tensor(g["controls"], device=DEV)[None]
+    robs = [make_robot(torch, g), make_robot(torch, g)]
+    kw = dict(lr=0.2, patience=2, factor=0.5)
+    dev_tr = KnodeTrainer(robs[0], traj, controls, [3, 5, 7, 9], **kw)
+    ref_tr = KnodeTrainer(robs[1], traj, controls, [3, 5, 7, 9], device_plateau=False, **kw)
+    assert dev_tr.device_plateau and not ref_tr.device_plateau
+    E = 60
+    lrs_ref, losses_ref = [], []
+    for e in range(E):
+        dev_tr.step(sync_loss=False)  # nothing in here waits for the device
+        losses_ref.append(ref_tr.step())
+        lrs_ref.append(ref_tr.scheduler.get_last_lr()[0])
+    losses_dev = dev_tr.losses()
+    assert len(losses_dev) == E
+    # the schedule must have fired, and identically: replay torch's scheduler on the DEVICE run's own losses
+    probe = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=kw["lr"])
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(probe, "min", patience=kw["patience"], factor=kw["factor"])
+    for v in losses_dev:
+        sch.step(v)
+    assert dev_tr.scheduler.get_last_lr()[0] == pytest.approx(sch.get_last_lr()[0], rel=1e-12)
+    assert sch.get_last_lr()[0] < kw["lr"] / 3.9, "the schedule was meant to reduce the rate at least twice"
+    sd = dev_tr.scheduler.state_dict()
+    assert sd["reductions"] >= 2 and sd["best"] == pytest.approx(min(losses_dev), rel=1e-6)
+    # and the two runs stay together while their schedules agree
+    same = 0
+    while same < E and abs(losses_dev[same] - losses_ref[same]) <= 2e-4 * abs(losses_ref[same]):
+        same += 1
+    assert same >= 10, (losses_dev[:12], losses_ref[:12])
+    assert dev_tr.optimizer_state_dict()["param_groups"][0]["lr"] == pytest.approx(sch.get_last_lr()[0], rel=1e-12)
+
+
 def test_no_nn_self_consistency(torch_cuda):
     """with the MLP off the predictor reproduces the state the
     simulator produced (same Euler rule), and matches the reference's own output."""
