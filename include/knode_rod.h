@@ -130,6 +130,17 @@ int kr_destroy(kr_handle* h);
  *                    advanced by several calls, each continuing where the previous one stopped
  *                    (states[0] of a call = the last state of the one before).  Setting it to 0 drops
  *                    the stored state.
+ *   "residual_test"  1 (default) / 0: the multiple-shooting kernels may accept a storing sweep from its RESIDUAL alone.
+ *                    The documented stopping rule is on the Newton update (|dG|, |dY_i| <= tol max(1, |.|)); forming
+ *                    that update costs a condensation.  With the option on, a storing sweep that follows an update
+ *                    <= 1e-2 is first judged by amp x |residual|, amp = |update| / |residual| measured at the preceding
+ *                    full iteration of the same solve, and accepted when 256 x that estimate is below the tolerance
+ *                    (the two residuals point in different directions, so the ratio is only indicative: audited at
+ *                    most 39 x off over 8 workloads x 1024 rods x 300 steps - DESIGN.md section 4; the factor 256 is
+ *                    the margin).  status still reports "converged"; with 0 every accepted sweep carries a measured
+ *                    update (Newton, or chord within 1 %) below the tolerance, at ~5 % of the throughput.
+ *   "overlap"        1 (default) / 0: persistent form only - verify step t on spare lanes of the Jacobian sweep of
+ *                    step t + 1 (kr_mso_impl.hpp; Euler sweeps, MLP off, diagonal material matrices)
  *   "predictor"      0..8: how kr_simulate_batch may form the initial guess of each step (default 8;
  *                    0 = the reference's warm start).  1..7: highest order of polynomial time
  *                    extrapolation; the persistent kernel picks, rod by rod and step by step, the
@@ -215,7 +226,9 @@ int kr_residual_mid_batch(kr_handle* h, int64_t B, int scheme, const void* G, co
  * swept state into state_next.  G[B][6] is read as the initial guess and
  * overwritten with the solution.  tol: stop when |dG|_inf <= tol*max(1,|G|_inf)
  * (<=0 selects 1e-8 for f64 - the class of the reference's fsolve xtol=1.49e-8 - and 1e-5 for f32); maxit <= 0 selects 30.
- * status[B], iters[B] (int32) may be NULL.
+ * status[B], iters[B] (int32) may be NULL.  A step that plain Newton does not solve within maxit sweeps (from the
+ * predicted and from the caller's start) is redone by damped Newton with its OWN cap of 8 x maxit sweeps
+ * (backtracking rejections count as sweeps); iters reports the sum of both phases.
  * Initial guess: predictor = 0 starts Newton from the caller's G (the
  * reference's warm start, knode.py:89); 1 / 2 extrapolate the unknowns linearly /
  * quadratically in time from state_cur, state_prev (and state_prev2, may be

@@ -86,6 +86,7 @@ struct kr_handle {
   int fused_mlp = 1;         // training: fused MFMA forward/backward kernels (kr_mlp_fused.hip) when the shape allows
   int mfma_mlp = 1;          // evaluate the in-sweep MLP on the matrix cores when its shape allows
   int persistent = 1;        // kr_simulate_batch: run all steps in one launch when the multiple-shooting kernel applies
+  int residual_test = 1;     // accept a storing sweep from its residual alone when the estimate is 256 x below the tolerance
   int overlap = 1;           // ... and overlap the verifying sweep of step t with the Jacobian sweep of step t + 1 (kr_mso_impl.hpp)
   int last_overlap = 0;      // the last kr_simulate_batch ran the overlapped kernel
   void* resume_buf = nullptr;  // int32 per rod (SimArgs::resume)
@@ -153,6 +154,7 @@ struct StepArgs {
   int pred_reset = 0;     // first step of a simulate call: build the predictor from cur / prev
   int pred_has_prev = 0;  // ... prev is a real earlier state
   int pred_limit = 0;     // the handle's "predictor" option
+  int residual_test = 1;  // option "residual_test": see kr_set_option (knode_rod.h)
   // residual mode, RK4 only: explicit midpoint histories [B][N][KR_SLOTS] (record j = between grid points j and j + 1);
   // nullptr = the linear interpolation knode.simulate forms (knode.py:80-81)
   const T* mid = nullptr;
@@ -184,6 +186,7 @@ struct SimArgs {
   // (T_steps: all done); the one-wavefront persistent kernel launched behind it with the same arguments resumes
   // exactly there with its full fallback ladder.  nullptr: every rod starts at step 0.
   int32_t* resume = nullptr;
+  int residual_test = 1;  // option "residual_test"
 };
 
 // returns 1 when the persistent form does not apply

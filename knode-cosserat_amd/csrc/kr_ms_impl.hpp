@@ -304,6 +304,7 @@ struct MsSolveArgs {
   // persistent several-wavefront kernel (kr_msw_impl.hpp): where a storing sweep also leaves the twelve leading slots
   // of every record, [N][12] in LDS (nullptr: nowhere)
   T* lead12 = nullptr;
+  bool quick_ok = true;  // option "residual_test": the residual test below may accept a storing sweep
 };
 
 // Scaled maximum norm of the residual of a sweep - the interface jumps E_g - Y_{g+1} (19 rows each) and the tip
@@ -493,7 +494,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     // a tolerance of 1e-8, so the factor costs nothing there.  Otherwise the chord check decides as before.
     bool quick = false;
     float quick_est = 0.f;
-    if (!NN && chord && amp > 0.f) {  // (with the MLP on the Jacobian is approximate and the ratio not audited)
+    if (!NN && S.quick_ok && chord && amp > 0.f) {  // (with the MLP on the Jacobian is approximate and the ratio not audited)
       {
         T er[19];
         state_to_rows(y, er);
@@ -1284,6 +1285,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
   S.tip = A.tip ? A.tip + rod * A.tip_stride : nullptr;
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
   S.kappa = T(0);
+  S.quick_ok = A.residual_test != 0;
   int it, status;
   MsStamps stamps;
   if (A.pred) {
@@ -1402,6 +1404,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   }
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
   S.kappa = Q.kappa;
+  S.quick_ok = A.residual_test != 0;
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
       rn = wave_max_nonneg(rn);
       const float est = ampB * rn;
       // residual test (kr_ms_impl.hpp: audited factor 256 on the measured update / residual ratio)
-      bool accepted = ampB > 0.f && T(256) * (T)est <= tol;
+      bool accepted = A.residual_test != 0 && ampB > 0.f && T(256) * (T)est <= tol;
       float dnv = est;
 #ifdef KR_MS_STAMPS
       if (accepted) st.quick += 1;

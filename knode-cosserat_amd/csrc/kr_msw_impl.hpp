@@ -476,7 +476,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 
     // ---- residual test of a storing sweep that follows a small update (kr_ms_impl.hpp, ms_newton) ------------
     float res_local = 0.f;
-    if (storing && amp > 0.f && dn_prev > T(0) && dn_prev <= T(1e-2)) {
+    if (S.quick_ok && storing && amp > 0.f && dn_prev > T(0) && dn_prev <= T(1e-2)) {
       {
         T er[19];
         state_to_rows(y, er);
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
   }
   S.out_rod = A.next + rod * rod_elems;
   S.tip = A.tip ? A.tip + rod * A.tip_stride : nullptr;
-  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit; S.quick_ok = A.residual_test != 0;
   S.kappa = T(0);
   const int ne = R.K * 19;
   T* Xl = L.Xs + R.g0 * 19;
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
   if (img && A.pred_load) ms_pred_load<T>(Q, img, lane);
   else mswp_init<T>(Q, lane, ne, R.g0, N, P, s0, sp, A.prev_init != nullptr, A.predictor);
   MsSolveArgs<T> S;
-  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
+  S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit; S.quick_ok = A.residual_test != 0;
   S.kappa = Q.kappa;
   T Gguess = (wave == 0 && lane < 6) ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;

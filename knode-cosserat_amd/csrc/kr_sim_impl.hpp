@@ -419,6 +419,10 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
   // from the caller's guess with backtracking - every update is taken as G - lam d, lam halved until the residual
   // norm has decreased (what the CPU oracle's newton_shoot does).  Same root, same stopping rule.
   bool damped = false, have_trial = false;
+  // Sweep counters of THIS rod: `it` counts the plain phase, `itd` the damped one (its own cap, 8 x maxit); a rod
+  // that is done stops counting although its lanes keep sweeping with the rest of the wavefront.  A.iters = it + itd.
+  bool redo = false;  // this rod is in the damped phase
+  int itd = 0;
   int maxit = A.maxit;
   T Gold[6], dsv[6];
 #pragma unroll
@@ -500,7 +504,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
     T res[6];
     res[0] = P.Ftip[0] - y.n.x; res[1] = P.Ftip[1] - y.n.y; res[2] = P.Ftip[2] - y.n.z;
     res[3] = P.Mtip[0] - y.m.x; res[4] = P.Mtip[1] - y.m.y; res[5] = P.Mtip[2] - y.m.z;
-    ++it;
+    if (!done && !flush) { if (redo) ++itd; else ++it; }
+    const int cnt = redo ? itd : it;  // sweeps of the phase this rod is in, against that phase's cap
     if (A.mode == 1) {
       if (valid && col == 0) {
 #pragma unroll
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
     }
     if (!done) {
       const T keep = T(1) - T(1e-4) * lam;
-      if (damped && have_trial && !(nr <= nr_old * keep * keep) && lam > T(1.0 / 1024.0) && it < maxit) {
+      if (damped && have_trial && !(nr <= nr_old * keep * keep) && lam > T(1.0 / 1024.0) && cnt < maxit) {
         lam *= T(0.5);  // rejected trial point: shorter step along the same direction
 #pragma unroll
         for (int k = 0; k < 6; ++k) G[k] = Gold[k] - lam * dsv[k];
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
         if (predict_final<T>(dn / gn, dn_prev, A.tol, A.tolA)) storing = true;
         dn_prev = dn / gn;
         stored = false;
-        if (it >= maxit) {
+        if (cnt >= maxit) {
           done = true;
           status = KR_ST_MAXIT;
         }
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
         if (status != KR_ST_CONVERGED) {
           done = false; stored = false; storing = true; have_trial = false;
           status = KR_ST_MAXIT;
-          it = 0;
+          redo = true;
           maxit = 8 * A.maxit;
           dn_prev = T(-1);
 #pragma unroll
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const RodConst<T> P, const S
 #pragma unroll
     for (int k = 0; k < 6; ++k) A.G[rod * 6 + k] = G[k];
     if (A.status) A.status[rod * A.st_stride] = status;
-    if (A.iters) A.iters[rod * A.st_stride] = it;
+    if (A.iters) A.iters[rod * A.st_stride] = it + itd;
   }
 }
 

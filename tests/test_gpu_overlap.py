@@ -207,3 +207,26 @@ def test_full_matrices_fall_back(torch_cuda, monkeypatch):
     ctl = torch.as_tensor(_sine(3, 6, r.del_t, 4), device=DEV).contiguous()
     a = _run(torch, h, ctl, torch.float64, 1)
     assert a["ran"] == 0 and h.get_option("last_sim_path") == 2 and np.all(a["status"] == 0)
+
+
+@pytest.mark.parametrize("mode", ["persistent", "overlap", "multi"])
+def test_residual_test_option(torch_cuda, monkeypatch, mode):
+    """Option "residual_test" = 0: no storing sweep is accepted from its residual alone - every accepted state carries
+    a measured update (Newton or chord) below the tolerance.  Same states as with the default (the option only changes
+    how acceptance is decided), for the plain persistent kernel, the overlapped one and one launch per step."""
+    torch = torch_cuda
+    set_mode_env(monkeypatch, mode)
+    r = make_robot(None, 100)
+    h = r._native()
+    assert h.get_option("residual_test") == 1
+    B, T = 32, 45
+    ctl = torch.as_tensor(_sine(B, T, r.del_t, 1235), device=DEV).contiguous()
+    ov = 1 if mode == "overlap" else 0
+    a = _run(torch, h, ctl, torch.float64, ov)
+    h.set_option("residual_test", 0)
+    b = _run(torch, h, ctl, torch.float64, ov)
+    h.set_option("residual_test", 1)
+    assert a["ran"] == ov and b["ran"] == ov
+    assert np.all(a["status"] == 0) and np.all(b["status"] == 0)
+    assert rel_l2(a["states"][T][..., :25], b["states"][T][..., :25]) < 1e-8
+    assert rel_l2(a["tip"], b["tip"]) < 1e-9
