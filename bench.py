@@ -304,6 +304,10 @@ def main():
         if wpr > 1:  # small batches: several wavefronts per rod (kr_msw_impl.hpp)
             kernel_name = (f"kr::msw_sim_kernel (persistent, {wpr} wavefronts per rod)" if persistent
                            else f"kr::msw_step_kernel ({wpr} wavefronts per rod)")
+        elif path == 2 and h.get_option("last_overlap"):
+            # kr_mso_impl.hpp: one sweep per step in the steady state; the plain persistent kernel is launched behind it
+            # for rods that left steps behind (none here: unconverged_rod_steps) and exits at once otherwise
+            kernel_name = "kr::mso_sim_kernel (persistent, overlapped steps, all K steps in one launch)"
         else:
             kernel_name = ("kr::step_kernel", "kr::ms_step_kernel",
                            "kr::ms_sim_kernel (persistent, all K steps in one launch)")[path] if path in (0, 1, 2) else "?"

@@ -49,7 +49,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 #ifdef KR_MS_STAMPS
-struct MsoStats { unsigned long long total = 0, sweeps = 0, merged = 0, quick = 0, chord = 0, rejects = 0, retries = 0, rebuilds = 0, t_sweep = 0, t_alg = 0, t_pred = 0; };
+struct MsoStats { unsigned long long total = 0, sweeps = 0, merged = 0, quick = 0, chord = 0, rejects = 0, retries = 0, rebuilds = 0, t_sweep = 0, t_alg = 0, t_pred = 0, t_verdict = 0, t_cond = 0, t_fin = 0, t_upd = 0; };
 #endif
 
 template <typename T, bool DIAG, int HS>
@@ -483,6 +483,11 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
     // =============================================================================================================
     // Newton update of step tA from the forward-difference sweep (kr_ms_impl.hpp, "full" branch)
     // =============================================================================================================
+#ifdef KR_MS_STAMPS
+    { unsigned long long t_; KR_STAMP(t_); st.t_verdict += t_ - tq; }
+    unsigned long long tq2;
+    KR_STAMP(tq2);
+#endif
     ++it;
     float res_full;
     {
@@ -585,7 +590,13 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
         updY[g - 1] = s;
       }
     }
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(st.t_cond, tq2);
+#endif
     dnf = finish(Xs, [](int g) { return g == 0 ? 0 : 7 + 17 * (g - 1); });
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(st.t_fin, tq2);
+#endif
     finite = dnf <= 3.0e38f;
     const T dn = (T)dnf;
     if (res_full > 0.f && finite) amp = dnf / res_full;
@@ -633,6 +644,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
       wave_sync_lds();
       dnB = dn; ampB = amp; belowB = below; itB = it; orderB = order;
       if (!pred_skip) ms_pred_update<T>(Q, order, KR_ST_CONVERGED, A.predictor, lane, XsB, stamps);
+#ifdef KR_MS_STAMPS
+      { unsigned long long t_; KR_STAMP(t_); st.t_upd += t_ - tq; }
+#endif
       tA += 1;
       fcB = fcA;
       if (tA < T_steps) {
@@ -666,6 +680,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
     dd[0] = te - t_begin; dd[1] = st.t_sweep; dd[2] = st.t_alg; dd[3] = st.t_pred; dd[4] = st.sweeps;
     dd[5] = st.merged; dd[6] = st.quick; dd[7] = st.chord; dd[8] = st.rejects; dd[9] = st.retries; dd[10] = st.rebuilds;
     dd[11] = (unsigned long long)resume_at;
+    dd[12] = st.t_verdict; dd[13] = st.t_cond; dd[14] = st.t_fin; dd[15] = st.t_upd;
   }
 #endif
 }

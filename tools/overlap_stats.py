@@ -27,7 +27,7 @@ h.simulate(ctl_all[:, WARM:].contiguous(), st, G, ring=True, prev_init=st[(WARM 
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = dbg.cpu().numpy().astype(np.float64)
 print(f"overlap ran: {h.get_option('last_overlap')}  wall {el / T * 1e6:.2f} us/step  unconverged {int((status != 0).sum())}")
-names = ["total", "t_sweep", "t_alg", "t_pred", "sweeps", "merged", "quick", "chord", "rejects", "retries", "rebuilds", "resume_at"]
+names = ["total", "t_sweep", "t_alg", "t_pred", "sweeps", "merged", "quick", "chord", "rejects", "retries", "rebuilds", "resume_at", "t_verdict", "t_cond(handover+chain+solve+updY)", "t_finish", "t_pred_update(copy+update)"]
 for k, n in enumerate(names):
     print(f"  {n:10s} per step: mean {d[:, k].mean() / T:10.3f}  max {d[:, k].max() / T:10.3f}")
 print("  ticks per sweep:", d[:, 1].sum() / d[:, 4].sum(), " per condensation:", d[:, 2].sum() / d[:, 4].sum(), " tick rate MHz", d[:, 0].max() / el / 1e6)
