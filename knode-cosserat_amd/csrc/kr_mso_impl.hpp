@@ -210,6 +210,21 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
     };
     T hv[HS];
     load_hist_vec<T, HS>(L.hist + (size_t)point_of(0) * HS, hv);
+    if (!merged) {
+      // plain forward-difference sweep (start-up, rough inputs, after a rejection): the branch-free body of
+      // kr_ms_impl.hpp, two grid points per trip so that the scheduler overlaps neighbours; every interval has
+      // sbase or sbase + 1 segments, so only the last grid point needs a predicate
+      auto fd_point = [&](int j, T dsl) __attribute__((always_inline)) {
+        RodState<T> k1;
+        V3<T> v, u;
+        ode_eval<T, DIAG>(Pc, y, hist_from<T, HS>(hv), fc, k1, v, u);
+        load_hist_vec<T, HS>(L.hist + (size_t)(j + 1) * HS, hv);  // (record N - 1 exists and is not used)
+        y = state_axpy(y, dsl, k1);
+      };
+#pragma unroll 2
+      for (int t = 0; t < R.sbase; ++t) fd_point(R.s_i + t, Pc.ds);
+      if (R.srem) fd_point(R.s_i + (R.len_i > R.sbase ? R.sbase : R.sbase - 1), R.len_i > R.sbase ? Pc.ds : T(0));
+    } else
 #pragma unroll 2
     for (int k = 0; k < trips; ++k) {
       const int kk = k - lag;
