@@ -224,20 +224,21 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
 #pragma unroll 2
       for (int t = 0; t < R.sbase; ++t) fd_point(R.s_i + t, Pc.ds);
       if (R.srem) fd_point(R.s_i + (R.len_i > R.sbase ? R.sbase : R.sbase - 1), R.len_i > R.sbase ? Pc.ds : T(0));
-    } else
-#pragma unroll 2
-    for (int k = 0; k < trips; ++k) {
-      const int kk = k - lag;
-      const bool live = act && kk >= 0 && kk < len_l;
-      const int j = point_of(k);
-      // leading slots of the previous state at the verifying lane's grid point: requested now, used after the
-      // arithmetic of this trip (the record written in the previous trip belongs to the grid point before)
-      T old[12];
-      if (merged) load_hist_vec<T, 12>(L.c12 + (size_t)j * 12, old);
-      RodState<T> k1;
-      V3<T> v, u;
-      ode_eval<T, DIAG>(Pc, y, hist_from<T, HS>(hv), fc, k1, v, u);
-      if (merged) {  // (wave-uniform)
+    } else {
+      // one trip of the merged sweep.  FULL: every active lane is inside its interval (no predicates, no clamped
+      // indices) - true for the trips MSO_LAG .. sbase - 1, i.e. all but the first and last few.
+      auto trip = [&](int k, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int kk = k - lag;
+        const bool live = FULL ? act : (act && kk >= 0 && kk < len_l);
+        const int j = FULL ? s_l + kk : point_of(k);
+        // leading slots of the previous state at the verifying lane's grid point: requested now, used after the
+        // arithmetic of this trip (the record written in the previous trip belongs to the grid point before)
+        T old[12];
+        load_hist_vec<T, 12>(L.c12 + (size_t)j * 12, old);
+        RodState<T> k1;
+        V3<T> v, u;
+        ode_eval<T, DIAG>(Pc, y, hist_from<T, HS>(hv), fc, k1, v, u);
         if (isB && live) {
           // the accepted-to-be state of step tB at grid point j: to HBM; its leading slots replace those of the state
           // before it in LDS, and the two together are the history record of step tB + 1 at j (knode.py:74-75)
@@ -259,13 +260,18 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T
           if constexpr (HS > 18) { hrec[18] = T(0); hrec[19] = T(0); }
           store_vec<T, HS>(L.hist + (size_t)j * HS, hrec);
         }
-      }
-      // history record of the next trip.  A forward-difference lane reads what a verifying lane wrote
-      // MSO_LAG - 1 trips ago (for MSO_LAG = 1: above, in this trip); a verifying lane reads a record it has not
-      // replaced yet.
-      load_hist_vec<T, HS>(L.hist + (size_t)point_of(k + 1) * HS, hv);
-      const T dsl = live ? Pc.ds : T(0);  // (a lane outside its range evaluates finite data and adds nothing)
-      y = state_axpy(y, dsl, k1);
+        // history record of the next trip.  A forward-difference lane reads what a verifying lane wrote
+        // MSO_LAG - 1 trips ago (for MSO_LAG = 1: above, in this trip); a verifying lane reads a record it has not
+        // replaced yet.  (FULL: j + 1 <= N - 1 is a valid record even where it lies past the lane's interval.)
+        load_hist_vec<T, HS>(L.hist + (size_t)(FULL ? j + 1 : point_of(k + 1)) * HS, hv);
+        const T dsl = live ? Pc.ds : T(0);  // (a lane outside its range evaluates finite data and adds nothing)
+        y = state_axpy(y, dsl, k1);
+      };
+      int k = 0;
+      for (; k < MSO_LAG && k < trips; ++k) trip(k, std::false_type{});
+#pragma unroll 2
+      for (; k < R.sbase; ++k) trip(k, std::true_type{});
+      for (; k < trips; ++k) trip(k, std::false_type{});
     }
 #ifdef KR_MS_STAMPS
     KR_STAMP_ADD(st.t_sweep, tq);
