@@ -31,7 +31,7 @@
 namespace kr {
 
 constexpr int MSO_B0 = 7 + 17 * (MS_P - 1);  // 58: first of the four lanes that re-integrate the step under verification
-constexpr int MSO_LAG = 2;  // grid points the verifying lanes run ahead of the lanes that consume their records (1 measures the same)
+constexpr int MSO_LAG = 1;  // grid points the verifying lanes run ahead of the lanes that consume their records (2: 3 % slower)
 static_assert(MSO_B0 + MS_P <= WAVE, "the verifying lanes must fit beside the forward-difference lanes");
 
 template <typename T, int HS>
