@@ -12,13 +12,20 @@ from knode import setup_robot
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 WARM = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+KIND = sys.argv[4] if len(sys.argv) > 4 else "sine"
 N = 100
 dev = "cuda:0"; dt = torch.float64
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
 h = r._native(); h.set_option("waves_per_rod", 1); h.set_option("keep_predictor", 1)
 dbg = torch.zeros((B, 24), dtype=torch.int64, device=dev)
 kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
-ctl_all = torch.as_tensor(bench.rank_controls(B, 1, 0, WARM + T, r.del_t), device=dev).contiguous()
+if KIND == "sine":
+    ctl_np = bench.rank_controls(B, 1, 0, WARM + T, r.del_t)
+elif KIND == "random":  # fresh random tensions every step (physics_controls.py 'random')
+    ctl_np = 5.0 + 5.0 * np.random.default_rng(5).uniform(size=(B, WARM + T, 4))
+else:  # step
+    ctl_np = np.full((B, WARM + T, 4), 5.0); ctl_np[:, WARM + T // 3:, 0] += 1.0; ctl_np[:, WARM + T // 3:, 3] += 1.0
+ctl_all = torch.as_tensor(ctl_np, device=dev).contiguous()
 st = h.new_state(B, dt, n_slots=3); h.init_straight(st[0]); G = torch.zeros((B, 6), dtype=dt, device=dev)
 status = torch.full((B, T), -1, dtype=torch.int32, device=dev)
 h.simulate(ctl_all[:, :WARM].contiguous(), st, G, ring=True)
@@ -26,7 +33,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 h.simulate(ctl_all[:, WARM:].contiguous(), st, G, ring=True, prev_init=st[(WARM - 1) % 3], status=status)
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 d = dbg.cpu().numpy().astype(np.float64)
-print(f"overlap ran: {h.get_option('last_overlap')}  wall {el / T * 1e6:.2f} us/step  unconverged {int((status != 0).sum())}")
+print(f"[{KIND}] overlap ran: {h.get_option('last_overlap')}  wall {el / T * 1e6:.2f} us/step  unconverged {int((status != 0).sum())}")
 names = ["total", "t_sweep", "t_alg", "t_pred", "sweeps", "merged", "quick", "chord", "rejects", "retries", "rebuilds", "resume_at", "t_verdict", "t_cond(handover+chain+solve+updY)", "t_finish", "t_pred_update(copy+update)"]
 for k, n in enumerate(names):
     print(f"  {n:10s} per step: mean {d[:, k].mean() / T:10.3f}  max {d[:, k].max() / T:10.3f}")
