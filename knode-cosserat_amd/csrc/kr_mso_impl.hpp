@@ -52,8 +52,10 @@ __device__ __forceinline__ void wave_sync_lds() {
 struct MsoStats { unsigned long long total = 0, sweeps = 0, merged = 0, quick = 0, chord = 0, rejects = 0, retries = 0, rebuilds = 0, t_sweep = 0, t_alg = 0, t_pred = 0, t_verdict = 0, t_cond = 0, t_fin = 0, t_upd = 0; };
 #endif
 
-template <typename T, bool DIAG, int HS>
-__global__ __launch_bounds__(WAVE * MS_WPB) void mso_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A) {
+// OCC: workgroups per CU the register allocation leaves room for.  OCC = 2 (fp32, batches beyond one rod per SIMD)
+// runs two rods on every SIMD, whose issue-bound sweeps and latency-bound algebra overlap (as kr_ms_impl.hpp's OCC).
+template <typename T, bool DIAG, int HS, int OCC = 1>
+__global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = Pc.N;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -713,14 +715,30 @@ int launch_mso_sim(kr_handle* h, const SimArgs<T>& a, hipStream_t s) {
   if (!P.diag || P.N - 1 < 2 * MS_P) return 1;
   const size_t smem = sizeof(T) * mso_lds_elems<T, HS>(P.N) * MS_WPB;
   if (smem > (size_t)h->lds_limit) return 1;
-  auto kern = mso_sim_kernel<T, true, HS>;
+  const dim3 grid((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), block(WAVE * MS_WPB);
+  if constexpr (sizeof(T) == 4) {
+    // fp32, more rods than SIMDs, and two workgroups fit the LDS of a CU: two wavefronts per SIMD
+    if (a.B > 1024 && 2 * smem <= (size_t)h->lds_limit) {
+      auto kern2 = mso_sim_kernel<T, true, HS, 2>;
+      static thread_local size_t configured2 = 0;
+      if (smem > 48 * 1024 && smem > configured2) {
+        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)smem));
+        configured2 = smem;
+      }
+      hipLaunchKernelGGL(kern2, grid, block, smem, s, P, a);
+      KR_HIP(hipGetLastError());
+      return KR_OK;
+    }
+  }
+  auto kern = mso_sim_kernel<T, true, HS, 1>;
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
     configured = smem;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a);
+  hipLaunchKernelGGL(kern, grid, block, smem, s, P, a);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }
