@@ -384,123 +384,37 @@ __device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status,
   if (Q.avail < MS_HLEV - 1) ++Q.avail;
 }
 
-// ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
-template <typename T, bool DIAG, int W>
-__device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
-                                          V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps) {
-  constexpr int P = MswGeo<W>::P;
-  const int N = Pc.N;
-  const int wave = R.w;
+// ---- one full Newton update of the rod, distributed over its W wavefronts ----------------------------------------
+// From the end states of a sweep (y: this lane's; hstep: its forward-difference step) to the update of every unknown
+// this wavefront owns and the norms that steer the iteration - everything between a sweep and the decision what to do
+// next.  Every wavefront of the workgroup calls it (it contains workgroup barriers).  Leaves the forward-difference
+// columns in Es, the updates in L.dY / U, and returns in U.dnf / U.res_local the workgroup-wide scaled maximum norms
+// of the update and of the sweep's residual.
+template <typename T>
+struct MswUpd {
+  float dnf, res_local;
+  T updP, xsP, updG, xsG, updR[4], xsR[4];
+  int pg, pprow;
+  bool plane, glane;
+};
+template <typename T, int W>
+__device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRole& R, int lane, const RodState<T>& y,
+                                             T hstep, MswUpd<T>& U
 #ifdef KR_MS_STAMPS
-  unsigned long long tq;
-  KR_STAMP(tq);
+                                             , MsStamps& stamps, unsigned long long& ta
 #endif
+) {
+  constexpr int P = MswGeo<W>::P;
+  const int wave = R.w;
   T* Xs = L.Xs;
   T* Es = L.Es + (size_t)wave * ((64 * 19 + 3) & ~3);
   T* Lt = L.Lt + (size_t)wave * 2 * 19 * MSW_LT_LD;
   float* redf = reinterpret_cast<float*>(L.red);
-  const int iv = R.iv, col = R.col;
+  const int col = R.col;
   const bool idle = R.idle;
   const int kp = lane & 3;
   const int r = 3 + (lane >> 2);
-  const bool last_wave = wave == W - 1;
-  bool storing = false, flush = false;
-  int status = KR_ST_MAXIT;
-  it = 0;
-  T dn_prev = T(-1);
-  const T kappa_in = S.kappa;
-  bool below = false;
-  float amp = -1.f;  // |update| / |residual| of the last full iteration of this solve (residual test, see ms_newton)
-
-  while (true) {
-    // ---- start state of this lane, forward-difference step of its column -------------------------------
-    T yr[19];
-#pragma unroll
-    for (int q = 0; q < 19; ++q) yr[q] = Xs[iv * 19 + q];
-    const T hstep = col > 0 ? S.fd_eps * fmax(fabs(Xs[iv * 19 + (R.comp > 0 ? R.comp : 3)]), T(1)) : T(1);
-#pragma unroll
-    for (int q = 3; q < 19; ++q) yr[q] += q == R.comp ? hstep : T(0);
-    RodState<T> y = rows_to_state(yr);
-    const bool st = (storing || flush) && col == 0 && !idle;
-
-    // ---- sweep over this lane's sub-interval (explicit Euler, cosserat_ode.py:198-201) ------------------
-    T hv[HS_LEAN];
-    load_hist_vec<T, HS_LEAN>(L.hist + (size_t)R.s_i * HS_LEAN, hv);
-    auto point = [&](auto store_tag, int j) __attribute__((always_inline)) {
-      constexpr bool STORE = decltype(store_tag)::value;
-      RodState<T> k1;
-      V3<T> v, u;
-      ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
-      if constexpr (STORE) {
-        if (st) {
-          T rec[KR_SLOTS];
-          record_from(y, v, u, rec);
-          store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
-          if (S.lead12) {
-            T lead[12];
-#pragma unroll
-            for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-            store_vec<T, 12>(S.lead12 + (size_t)j * 12, lead);
-          }
-        }
-      }
-      load_hist_vec<T, HS_LEAN>(L.hist + (size_t)(j + 1) * HS_LEAN, hv);
-      y = state_axpy(y, Pc.ds, k1);
-    };
-    if (storing || flush) {
-      for (int t = 0; t < R.sbase; ++t) point(std::true_type{}, R.s_i + t);
-      if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase);
-    } else {
-#pragma unroll KR_MS_UNROLL
-      for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t);
-      if (R.len_i > R.sbase) point(std::false_type{}, R.s_i + R.sbase);
-    }
-    if (st && iv == P - 1) {
-      T rec[KR_SLOTS];
-      record_from(y, S.vlast, S.ulast, rec);
-      store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
-      if (S.lead12) {
-        T lead[12];
-#pragma unroll
-        for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-        store_vec<T, 12>(S.lead12 + (size_t)(N - 1) * 12, lead);
-      }
-      if (S.tip) { S.tip[0] = y.p.x; S.tip[1] = y.p.y; S.tip[2] = y.p.z; }
-    }
-    if (flush) break;
-    ++it;
-#ifdef KR_MS_STAMPS
-    KR_STAMP_ADD(stamps.sweep, tq);
-    unsigned long long ta = tq;
-#endif
-
-    // ---- residual test of a storing sweep that follows a small update (kr_ms_impl.hpp, ms_newton) ------------
-    float res_local = 0.f;
-    if (S.quick_ok && storing && amp > 0.f && dn_prev > T(0) && dn_prev <= T(1e-2)) {
-      {
-        T er[19];
-        state_to_rows(y, er);
-        if (col == 0 && !idle) {
-#pragma unroll
-          for (int q = 0; q < 19; ++q) Es[lane * 19 + q] = er[q];
-        }
-      }
-      wave_sync();
-      const float rn = msw_max<W>(msw_residual_local<T, W>(Es, Xs, L.cold, R, lane), redf, wave, lane);
-      const float est = amp * rn;
-#ifdef KR_QUICK_AUDIT
-      stamps.qn = (double)est;  // compared with the update below
-#else
-      if (T(256) * (T)est <= S.tol) {  // (NaN compares false)
-        status = KR_ST_CONVERGED;
-        if (!below && dn_prev > T(0)) {
-          const T floor_dn = T(64) * (sizeof(T) == 8 ? T(2.2e-16) : T(1.2e-7));
-          S.kappa = fmin(fmax(fmax((T)est, floor_dn) * fast_rcp(dn_prev * dn_prev), T(1e-4)), T(1));
-        }
-        break;
-      }
-#endif
-    }
+  float res_local = 0.f;
     // ---- end states and forward-difference columns of this wavefront's intervals -------------------------
     {
       T er[19];
@@ -794,6 +708,151 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       dnf = fmaxf(dnf, update_ratio(updG, xsG));
     }
     msw_max2<W>(dnf, res_local, redf, wave, lane);
+  U.dnf = dnf; U.res_local = res_local;
+  U.updP = updP; U.xsP = xsP; U.updG = updG; U.xsG = xsG;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { U.updR[k] = updR[k]; U.xsR[k] = xsR[k]; }
+  U.pg = pg; U.pprow = pprow; U.plane = plane; U.glane = glane;
+}
+// adds the update msw_condense left in U to the unknowns this wavefront owns
+template <typename T, int W>
+__device__ __forceinline__ void msw_apply(const MswLds<T, W>& L, const MswRole& R, int lane, const MswUpd<T>& U) {
+  constexpr int P = MswGeo<W>::P;
+  T* Xs = L.Xs;
+  if (U.plane) Xs[U.pg * 19 + U.pprow] = U.xsP + U.updP;
+  if (U.glane) Xs[0 * 19 + 7 + (lane - (WAVE - 6))] = U.xsG + U.updG;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = R.w == 0 ? 1 + k : R.g0 + k;
+    if (k < 3 && g < P && (lane >> 4) == k) Xs[g * 19 + 3 + (lane & 15)] = U.xsR[k] + U.updR[k];
+  }
+}
+
+// ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
+template <typename T, bool DIAG, int W>
+__device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
+                                          V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps) {
+  constexpr int P = MswGeo<W>::P;
+  const int N = Pc.N;
+  const int wave = R.w;
+#ifdef KR_MS_STAMPS
+  unsigned long long tq;
+  KR_STAMP(tq);
+#endif
+  T* Xs = L.Xs;
+  T* Es = L.Es + (size_t)wave * ((64 * 19 + 3) & ~3);
+  T* Lt = L.Lt + (size_t)wave * 2 * 19 * MSW_LT_LD;
+  float* redf = reinterpret_cast<float*>(L.red);
+  const int iv = R.iv, col = R.col;
+  const bool idle = R.idle;
+  const int kp = lane & 3;
+  const int r = 3 + (lane >> 2);
+  const bool last_wave = wave == W - 1;
+  bool storing = false, flush = false;
+  int status = KR_ST_MAXIT;
+  it = 0;
+  T dn_prev = T(-1);
+  const T kappa_in = S.kappa;
+  bool below = false;
+  float amp = -1.f;  // |update| / |residual| of the last full iteration of this solve (residual test, see ms_newton)
+
+  while (true) {
+    // ---- start state of this lane, forward-difference step of its column -------------------------------
+    T yr[19];
+#pragma unroll
+    for (int q = 0; q < 19; ++q) yr[q] = Xs[iv * 19 + q];
+    const T hstep = col > 0 ? S.fd_eps * fmax(fabs(Xs[iv * 19 + (R.comp > 0 ? R.comp : 3)]), T(1)) : T(1);
+#pragma unroll
+    for (int q = 3; q < 19; ++q) yr[q] += q == R.comp ? hstep : T(0);
+    RodState<T> y = rows_to_state(yr);
+    const bool st = (storing || flush) && col == 0 && !idle;
+
+    // ---- sweep over this lane's sub-interval (explicit Euler, cosserat_ode.py:198-201) ------------------
+    T hv[HS_LEAN];
+    load_hist_vec<T, HS_LEAN>(L.hist + (size_t)R.s_i * HS_LEAN, hv);
+    auto point = [&](auto store_tag, int j) __attribute__((always_inline)) {
+      constexpr bool STORE = decltype(store_tag)::value;
+      RodState<T> k1;
+      V3<T> v, u;
+      ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
+      if constexpr (STORE) {
+        if (st) {
+          T rec[KR_SLOTS];
+          record_from(y, v, u, rec);
+          store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
+          if (S.lead12) {
+            T lead[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+            store_vec<T, 12>(S.lead12 + (size_t)j * 12, lead);
+          }
+        }
+      }
+      load_hist_vec<T, HS_LEAN>(L.hist + (size_t)(j + 1) * HS_LEAN, hv);
+      y = state_axpy(y, Pc.ds, k1);
+    };
+    if (storing || flush) {
+      for (int t = 0; t < R.sbase; ++t) point(std::true_type{}, R.s_i + t);
+      if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase);
+    } else {
+#pragma unroll KR_MS_UNROLL
+      for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t);
+      if (R.len_i > R.sbase) point(std::false_type{}, R.s_i + R.sbase);
+    }
+    if (st && iv == P - 1) {
+      T rec[KR_SLOTS];
+      record_from(y, S.vlast, S.ulast, rec);
+      store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+      if (S.lead12) {
+        T lead[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+        store_vec<T, 12>(S.lead12 + (size_t)(N - 1) * 12, lead);
+      }
+      if (S.tip) { S.tip[0] = y.p.x; S.tip[1] = y.p.y; S.tip[2] = y.p.z; }
+    }
+    if (flush) break;
+    ++it;
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.sweep, tq);
+    unsigned long long ta = tq;
+#endif
+
+    // ---- residual test of a storing sweep that follows a small update (kr_ms_impl.hpp, ms_newton) ------------
+    float res_local = 0.f;
+    if (S.quick_ok && storing && amp > 0.f && dn_prev > T(0) && dn_prev <= T(1e-2)) {
+      {
+        T er[19];
+        state_to_rows(y, er);
+        if (col == 0 && !idle) {
+#pragma unroll
+          for (int q = 0; q < 19; ++q) Es[lane * 19 + q] = er[q];
+        }
+      }
+      wave_sync();
+      const float rn = msw_max<W>(msw_residual_local<T, W>(Es, Xs, L.cold, R, lane), redf, wave, lane);
+      const float est = amp * rn;
+#ifdef KR_QUICK_AUDIT
+      stamps.qn = (double)est;  // compared with the update below
+#else
+      if (T(256) * (T)est <= S.tol) {  // (NaN compares false)
+        status = KR_ST_CONVERGED;
+        if (!below && dn_prev > T(0)) {
+          const T floor_dn = T(64) * (sizeof(T) == 8 ? T(2.2e-16) : T(1.2e-7));
+          S.kappa = fmin(fmax(fmax((T)est, floor_dn) * fast_rcp(dn_prev * dn_prev), T(1e-4)), T(1));
+        }
+        break;
+      }
+#endif
+    }
+    MswUpd<T> U;
+#ifdef KR_MS_STAMPS
+    msw_condense<T, W>(L, R, lane, y, hstep, U, stamps, ta);
+#else
+    msw_condense<T, W>(L, R, lane, y, hstep, U);
+#endif
+    float dnf = U.dnf;
+    res_local = U.res_local;
     const bool finite = dnf <= 3.0e38f;
     const T dn = (T)dnf;
     if (finite && res_local > 0.f) amp = dnf / res_local;
@@ -817,13 +876,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       done = true;
       status = KR_ST_CONVERGED;
     } else {
-      if (plane) Xs[pg * 19 + pprow] = xsP + updP;
-      if (glane) Xs[0 * 19 + 7 + (lane - (WAVE - 6))] = xsG + updG;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int g = wave == 0 ? 1 + k : R.g0 + k;
-        if (k < 3 && g < P && (lane >> 4) == k) Xs[g * 19 + 3 + (lane & 15)] = xsR[k] + updR[k];
-      }
+      msw_apply<T, W>(L, R, lane, U);
       if (predict_final<T>(dn, dn_prev, S.tol, S.tolA)) storing = true;
       if (kappa_in > T(0) && T(4) * kappa_in * dn * dn <= S.tol) storing = true;
       dn_prev = dn;
