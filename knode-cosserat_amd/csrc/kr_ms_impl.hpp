@@ -1598,6 +1598,7 @@ template <typename T>
 int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>& a, hipStream_t s) {
   const RodConst<T>& P = consts<T>(h);
   if (h->ms_mode == 0 || h->persistent == 0) return 1;
+  h->last_overlap = 0;
   if (const int W = step_waves_per_rod<T>(h, scheme, use_nn, a.B, 0)) return launch_msw_sim<T>(h, W, a, s);  // several wavefronts per rod
   h->last_waves_per_rod = 1;
   const MlpDev<T>& M = mlpdev<T>(h);

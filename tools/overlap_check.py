@@ -44,7 +44,7 @@ def run(overlap, maxit=0):
     r.compute_intermediate_terms()
     h = r._native()
     h.set_option("overlap", overlap)
-    h.set_option("waves_per_rod", 1)
+    h.set_option("waves_per_rod", int(os.environ.get("KR_OC_WAVES", "1")))
     ctl = torch.as_tensor(controls(), device=dev).to(dt).contiguous()
     st = h.new_state(B, dt, n_slots=3)
     G = torch.zeros((B, 6), dtype=dt, device=dev)
@@ -59,6 +59,7 @@ def run(overlap, maxit=0):
         h.simulate(ctl, st, G, ring=True, tip=tip, status=status, maxit=maxit)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
+    print("   waves per rod:", h.get_option("last_waves_per_rod"), "path", h.get_option("last_sim_path"))
     return tip.double().cpu().numpy(), status.cpu().numpy(), best, h.get_option("last_overlap"), st[T % 3].double().cpu().numpy()
 
 

@@ -16,7 +16,7 @@ KIND = sys.argv[4] if len(sys.argv) > 4 else "sine"
 N = 100
 dev = "cuda:0"; dt = torch.float64
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
-h = r._native(); h.set_option("waves_per_rod", 1); h.set_option("keep_predictor", 1)
+h = r._native(); h.set_option("waves_per_rod", int(os.environ.get("KR_OC_WAVES", "1"))); h.set_option("keep_predictor", 1)
 dbg = torch.zeros((B, 24), dtype=torch.int64, device=dev)
 kn.check(h.lib.kr_debug_buffer(h._h, kn._ptr(dbg)))
 if KIND == "sine":
