@@ -229,6 +229,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
     } else {
       // one trip of the merged sweep.  FULL: every active lane is inside its interval (no predicates, no clamped
       // indices) - true for the trips MSO_LAG .. sbase - 1, i.e. all but the first and last few.
+      const bool lean = A.ring && tB + 4 <= T_steps;  // (the last three states of a call stay complete)
       auto trip = [&](int k, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int kk = k - lag;
@@ -246,10 +247,15 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
           // before it in LDS, and the two together are the history record of step tB + 1 at j (knode.py:74-75)
           T rec[KR_SLOTS];
           record_from(y, v, u, rec);
-          store_record(out_rod + (size_t)j * KR_SLOTS, rec);
           T lead[12];
 #pragma unroll
           for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+          // On a 3-slot ring nobody reads the states of the call's interior steps - except this kernel when it rolls a
+          // step back and the kernel launched behind it when it takes a rod over, and both need only the twelve leading
+          // slots of every record plus the full records at the interval starts and at the last grid point (predictor,
+          // z of the last point): interior records of interior steps go out lean (6 instead of 14 stores)
+          if (FULL && lean) store_vec<T, 12>(out_rod + (size_t)j * KR_SLOTS, lead);
+          else store_record(out_rod + (size_t)j * KR_SLOTS, rec);
           store_vec<T, 12>(L.c12 + (size_t)j * 12, lead);
           T hrec[HS];
 #pragma unroll

@@ -120,6 +120,14 @@ def test_rough_inputs_full_trajectory(torch_cuda, monkeypatch, kind, dtype):
     for t in (1, 24, 26, 30, 51, T):
         assert rel_l2(a["states"][t][..., :25], b["states"][t][..., :25]) < tol, t
     assert float(np.abs(a["states"][..., 25:]).max()) == 0.0  # padding slots
+    # the same on a 3-slot ring, where interior records go out lean (leading slots only) and a rolled-back step or a
+    # rod taken over by the second launch has to live with that: same tips, and the three states the ring ends with
+    # are complete and equal to the trajectory's
+    c = _run(torch, h, ctl_t, dt, 1, ring=True)
+    assert c["ran"] == 1 and np.all(c["status"] == 0)
+    assert np.array_equal(c["tip"], a["tip"])
+    for k in (T, T - 1, T - 2):
+        assert np.array_equal(c["states"][k % 3], a["states"][k])
 
 
 def test_hand_over_to_second_launch(torch_cuda, monkeypatch):
@@ -142,6 +150,11 @@ def test_hand_over_to_second_launch(torch_cuda, monkeypatch):
     assert np.all(np.isfinite(a["tip"]))
     # from the first failed step on both runs are the plain kernel's: equal to rounding of the start values
     assert rel_l2(a["tip"], b["tip"]) < 1e-6
+    # on a ring (lean interior records) the take-over reads what it needs all the same
+    ar = _run(torch, h, ctl, torch.float64, 1, maxit=2, ring=True)
+    assert np.array_equal(ar["status"], a["status"]) and rel_l2(ar["tip"], a["tip"]) < 1e-9
+    for k in (T, T - 1, T - 2):
+        assert rel_l2(ar["states"][k % 3][..., :25], a["states"][k][..., :25]) < 1e-9
     # and with the default cap everything converges again on the same handle
     c = _run(torch, h, ctl, torch.float64, 1)
     assert np.all(c["status"] == 0)
