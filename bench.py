@@ -251,9 +251,9 @@ def main():
     RAMP_A, RAMP_B = 0.5, 0.3
     ramp(RAMP_A)
     # First use of a kernel instantiation and of the handle's per-batch scratch costs host time (symbol lookup in a
-    # 10 MB code object, one hipMalloc) that must not sit between the timing events: two steps of the timed
-    # configuration on scratch state, on the handle that will run the timed launch (its predictor is not kept yet).
-    h.simulate(ramp_ctl[:, :2].contiguous(), ramp_st, ramp_g, ring=True)
+    # 10 MB code object, one hipMalloc: ~0.4 ms) that must not sit between the timing events: kr_simulate_prepare does
+    # that work ahead of time without launching anything, so the timed kernel still appears once in a trace.
+    h.simulate_prepare(B, tdt)
     torch.cuda.synchronize()
     cold = None
     if not args.no_cpu:

@@ -251,6 +251,10 @@ int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, c
  * which makes a second call continue a run exactly (it may point into the ring).
  * When the multiple-shooting kernel applies (see kr_set_option) all T steps run
  * in ONE launch: every wavefront keeps its rod's history in LDS / registers. */
+/* Optional: the host-side one-time work of the first kr_simulate_batch call for batches of B rods (per-batch scratch
+ * allocation, kernel lookup in the code object, LDS limits: ~0.4 ms) ahead of time, so that a latency-critical first
+ * call does not carry it.  Launches nothing.  No counterpart in the reference. */
+int kr_simulate_prepare(kr_handle* h, int64_t B, int dtype);
 int kr_simulate_batch(kr_handle* h, int64_t B, int64_t T, int scheme, const void* ctl, void* states, int ring,
                       void* G, void* tip, double tol, int maxit, int32_t* status, int use_nn,
                       const void* state_prev_init, int dtype, void* stream);

@@ -778,6 +778,17 @@ int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, c
   return launch_step<double>(h, scheme, use_nn, a, s);
 }
 
+int kr_simulate_prepare(kr_handle* h, int64_t B, int dtype) {
+  KR_CHECK_H(h);
+  KR_CHECK_DTYPE(dtype);
+  if (B <= 0) return KR_OK;
+  int rc = ensure_resume(h, B);
+  if (rc) return rc;
+  if (dtype == KR_F32) { rc = prepare_mso_sim<float>(h, B); if (rc != 1 && rc) return rc; rc = prepare_ms_sim<float>(h); }
+  else { rc = prepare_mso_sim<double>(h, B); if (rc != 1 && rc) return rc; rc = prepare_ms_sim<double>(h); }
+  return rc == 1 ? KR_OK : rc;
+}
+
 int kr_simulate_batch(kr_handle* h, int64_t B, int64_t T, int scheme, const void* ctl, void* states, int ring, void* G,
                       void* tip, double tol, int maxit, int32_t* status, int use_nn, const void* state_prev_init,
                       int dtype, void* stream) {

@@ -197,6 +197,11 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
 template <typename T>
 int launch_mso_sim(kr_handle* h, const SimArgs<T>& a, hipStream_t s);
 int ensure_resume(kr_handle* h, int64_t B);
+template <typename T>
+int prepare_mso_sim(kr_handle* h, int64_t B);
+// kr_sim_f32.hip / kr_sim_f64.hip: the same for the one-wavefront persistent kernel that runs behind it
+template <typename T>
+int prepare_ms_sim(kr_handle* h);
 
 // kr_mlp_fused.hip: fused fp32 MLP forward / backward for training
 bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad);

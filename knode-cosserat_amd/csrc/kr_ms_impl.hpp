@@ -1646,8 +1646,25 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
 
 #include "kr_msw_impl.hpp"  // several wavefronts per rod (uses everything above)
 
+namespace kr {
+// one-time host work of the first launch of the persistent Euler / MLP-off kernel, ahead of time (kr_simulate_prepare)
+template <typename T>
+int prepare_ms_sim(kr_handle* h) {
+  const RodConst<T>& P = consts<T>(h);
+  if (!P.diag) return 1;
+  auto kern = ms_sim_kernel<T, true, KR_EULER, hs_phys<T>(), false, 1>;
+  hipFuncAttributes fa;
+  KR_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+  const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, true);
+  if (smem > 48 * 1024 && smem <= (size_t)h->lds_limit)
+    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  return KR_OK;
+}
+}  // namespace kr
+
 #ifndef KR_MS_NO_INST  // (kr_mso_*.hip include this file for its device functions only)
 namespace kr {
+template int prepare_ms_sim<KR_SIM_T>(kr_handle*);
 template int launch_sim_persistent<KR_SIM_T>(kr_handle*, int, int, const SimArgs<KR_SIM_T>&, hipStream_t);
 template int step_waves_per_rod<KR_SIM_T>(kr_handle*, int, int, int64_t, int);
 

@@ -3,4 +3,5 @@
 #include "kr_mso_impl.hpp"
 namespace kr {
 template int launch_mso_sim<float>(kr_handle*, const SimArgs<float>&, hipStream_t);
+template int prepare_mso_sim<float>(kr_handle*, int64_t);
 }

@@ -714,6 +714,28 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
 #endif
 }
 
+// Host-side one-time work of the first launch, done ahead of time (kr_simulate_prepare): resolves the kernel in the
+// code object and sets its dynamic LDS limit.  Returns 1 when the kernel does not serve the handle's problem.
+template <typename T>
+int prepare_mso_sim(kr_handle* h, int64_t B) {
+  const RodConst<T>& P = consts<T>(h);
+  constexpr int HS = hs_phys<T>();
+  if (!P.diag || P.N - 1 < 2 * MS_P) return 1;
+  const size_t smem = sizeof(T) * mso_lds_elems<T, HS>(P.N) * MS_WPB;
+  if (smem > (size_t)h->lds_limit) return 1;
+  hipFuncAttributes fa;
+  if (sizeof(T) == 4 && B > 1024 && 2 * smem <= (size_t)h->lds_limit) {
+    auto k2 = mso_sim_kernel<T, true, HS, 2>;
+    KR_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k2)));
+    if (smem > 48 * 1024) KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  } else {
+    auto k1 = mso_sim_kernel<T, true, HS, 1>;
+    KR_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k1)));
+    if (smem > 48 * 1024) KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  }
+  return KR_OK;
+}
+
 template <typename T>
 int launch_mso_sim(kr_handle* h, const SimArgs<T>& a, hipStream_t s) {
   const RodConst<T>& P = consts<T>(h);

@@ -76,6 +76,7 @@ _PROTOS = {
     "kr_state_unpack50": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "kr_state_tip": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
     "kr_residual_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    "kr_simulate_prepare": (_int, [_vp, _i64, _int]),
     "kr_residual_mid_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kr_step_batch": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp, _vp, _int, _vp, _int, _int, _vp]),
     "kr_simulate_batch": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, C.c_double, _int, _vp, _int, _vp, _int, _vp]),
@@ -317,6 +318,10 @@ class Handle:
         check(self.lib.kr_step_batch(self._h, B, scheme, _ptr(prev), _ptr(cur), _ptr(nxt), _ptr(G), _ptr(tensions),
                                      float(tol), int(maxit), _ptr(status), _ptr(iters), int(bool(use_nn)),
                                      _ptr(prev2), int(predictor), dtype_code(G.dtype), _stream()))
+
+    def simulate_prepare(self, B, dtype):
+        """One-time host work of the first ``simulate`` call for batches of B rods, ahead of time (launches nothing)."""
+        check(self.lib.kr_simulate_prepare(self._h, int(B), dtype_code(dtype)))
 
     def get_option(self, name: str) -> int:
         v = C.c_int(0)
