@@ -11,8 +11,8 @@
 //     lanes 58..61   re-integrate step t from x1(t), one lane per sub-interval, and stream the state out
 // The start values of step t + 1 only need the UNKNOWNS of step t (known after its Newton update), and its BDF2
 // history record at grid point j only needs the state of step t at j - so the verifying lanes run one grid point
-// ahead, form the history record of the next step in place (LDS) and the forward-difference lanes pick it up one
-// trip later.  Per time step that leaves one sweep and one condensation; the discrete equations, the Newton
+// ahead, form the history record of the next step in place (LDS) and the forward-difference lanes pick it up at the
+// end of the same trip, for their next one.  Per time step that leaves one sweep and one condensation; the discrete equations, the Newton
 // iteration, the stopping rule and the stored states are those of kr_ms_impl.hpp (cosserat_ode.py:188-213 inside
 // knode.py:70-100).
 //
