@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): randomised comparison of the overlapped persistent kernel with the plain one - presets, grid
+sizes, batch sizes, input kinds, step counts, ring / trajectory, fp64 / fp32, iteration caps.  Prints one line per case
+and a summary; exits non-zero on a mismatch.   python tools/overlap_stress.py [cases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "knode-cosserat_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+from cosserat_ode import CosseratRod
+from knode import setup_robot
+import cosserat_oracle as orc
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+dev = "cuda:0"
+MODS = [None, "noair", "nsw", "short", "damping", "dampstiff", "lengthstiff", "youngs", "default"]
+bad = 0
+for c in range(cases):
+    mod = MODS[rng.integers(len(MODS))]
+    N = int(rng.integers(9, 102))
+    B = int(rng.choice([1, 3, 4, 5, 17, 64, 257, 1030]))
+    T = int(rng.choice([1, 2, 3, 4, 5, 9, 33, 70]))
+    kind = rng.choice(["sine", "step", "random", "const"])
+    f64 = bool(rng.integers(2))
+    ring = bool(rng.integers(2))
+    maxit = int(rng.choice([0, 0, 0, 3, 2]))
+    dt = torch.float64 if f64 else torch.float32
+    r = CosseratRod(use_fsolve=True)
+    if mod != "default":
+        setup_robot(r, mod)
+    r.N = N
+    r.compute_intermediate_terms()
+    if kind == "sine":
+        ctl = orc.batch_sine_controls(B, T, r.del_t, int(rng.integers(1 << 20)))
+    elif kind == "random":
+        ctl = 5.0 + 5.0 * rng.uniform(size=(B, T, 4))
+    elif kind == "step":
+        ctl = np.full((B, T, 4), 5.0); ctl[:, T // 2:, 0] += rng.uniform(0.3, 2.0, size=(B, 1)); ctl[:, T // 2:, 3] += 1.0
+    else:
+        ctl = np.tile(np.array([6.0, 5.0, 5.0, 6.0]), (B, T, 1))
+    if mod == "default":
+        ctl = ctl * 0.2  # (the class-default rod is thin: keep the loads in its range)
+    ctl_t = torch.as_tensor(ctl, device=dev).to(dt).contiguous()
+    h = r._native()
+    h.set_option("waves_per_rod", 1)
+    outs = []
+    for ov in (1, 0):
+        h.set_option("overlap", ov)
+        st = h.new_state(B, dt, n_slots=3 if ring else T + 1)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=dt, device=dev)
+        tip = torch.zeros((B, T, 3), dtype=dt, device=dev)
+        status = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+        h.simulate(ctl_t, st, G, ring=ring, tip=tip, status=status, maxit=maxit)
+        torch.cuda.synchronize()
+        last = st[T % 3] if ring else st[T]
+        outs.append((tip.double().cpu().numpy(), status.cpu().numpy(), last.double().cpu().numpy(), h.get_option("last_overlap"),
+                     h.get_option("last_sim_path")))
+    (t1, s1, l1, o1, p1), (t0, s0, l0, o0, p0) = outs
+    tol = 1e-7 if f64 else 5e-4
+    conv = (s0 == 0).all(axis=1) & (s1 == 0).all(axis=1)
+    den = np.linalg.norm(t0.reshape(B, -1), axis=1) + 1e-300
+    err = np.linalg.norm((t1 - t0).reshape(B, -1), axis=1) / den
+    e = float(err[conv].max()) if conv.any() else 0.0
+    el = float(np.abs(l1 - l0)[conv].max() / max(np.abs(l0).max(), 1e-300)) if conv.any() else 0.0
+    same_status = bool(np.array_equal(s1 != 0, s0 != 0)) if maxit == 0 else True
+    finite = bool(np.isfinite(t1[conv]).all())
+    ok = e < tol and el < tol and same_status and finite and o0 == 0 and (s1 >= 0).all() and (s1 <= 2).all()
+    bad += not ok
+    print(f"{'ok ' if ok else 'BAD'} case {c}: mod={mod} N={N} B={B} T={T} {kind} {'f64' if f64 else 'f32'} ring={int(ring)} maxit={maxit} "
+          f"overlap_ran={o1} path={p1} converged_rods={int(conv.sum())}/{B} unconv steps {int((s1 != 0).sum())}/{int((s0 != 0).sum())} tip err {e:.2e} state err {el:.2e}",
+          flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
