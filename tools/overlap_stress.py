@@ -57,7 +57,7 @@ for c in range(cases):
         outs.append((tip.double().cpu().numpy(), status.cpu().numpy(), last.double().cpu().numpy(), h.get_option("last_overlap"),
                      h.get_option("last_sim_path")))
     (t1, s1, l1, o1, p1), (t0, s0, l0, o0, p0) = outs
-    tol = 1e-7 if f64 else 5e-4
+    tol = (1e-7 if maxit == 0 else 1e-6) if f64 else 5e-4  # (with an iteration cap the two kernels reach the tolerance by different routes)
     conv = (s0 == 0).all(axis=1) & (s1 == 0).all(axis=1)
     den = np.linalg.norm(t0.reshape(B, -1), axis=1) + 1e-300
     err = np.linalg.norm((t1 - t0).reshape(B, -1), axis=1) / den
