@@ -1362,6 +1362,11 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   const int wv = threadIdx.x / WAVE;
   const int64_t rod = (int64_t)blockIdx.x * MS_WPB + wv;
   if (rod >= A.B) return;  // whole wavefront; there is no workgroup barrier in this kernel
+  // second launch of the two-launch form (kr_mso_impl.hpp): take over where the overlapped kernel stopped - a rod
+  // it finished leaves at once
+  const int64_t t0 = A.resume ? (int64_t)A.resume[rod] : 0;
+  if (t0 >= A.T_steps) return;
+  const bool resumed = t0 > 0;
   const size_t rod_elems = (size_t)N * KR_SLOTS;
   const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, true, NN), N, true, NN);
   const MsRole R = ms_role(lane, N);
@@ -1372,10 +1377,6 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   // registers (regP), both indexed lane-per-grid-point: the BDF2 history of the next step never
   // touches HBM
   T regP[MS_NPL][12];
-  // second launch of the two-launch form (kr_mso_impl.hpp): take over where the overlapped kernel stopped
-  const int64_t t0 = A.resume ? (int64_t)A.resume[rod] : 0;
-  if (t0 >= A.T_steps) return;
-  const bool resumed = t0 > 0;
   const T* s0 = A.states + (A.ring ? t0 % 3 : t0) * A.slot_elems + rod * rod_elems;
   const T* sp = resumed ? A.states + (A.ring ? (t0 - 1) % 3 : t0 - 1) * A.slot_elems + rod * rod_elems
                         : (A.prev_init ? A.prev_init + rod * rod_elems : s0);
