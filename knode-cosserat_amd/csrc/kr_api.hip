@@ -44,6 +44,19 @@ int ensure_resume(kr_handle* h, int64_t B) {
   return KR_OK;
 }
 
+int ensure_hist_ws(kr_handle* h, size_t bytes) {
+  if (bytes <= h->hist_ws_cap) return KR_OK;
+  if (h->hist_ws) {
+    KR_HIP(hipDeviceSynchronize());
+    KR_HIP(hipFree(h->hist_ws));
+    h->hist_ws = nullptr;
+    h->hist_ws_cap = 0;
+  }
+  KR_HIP(hipMalloc(&h->hist_ws, bytes + bytes / 4));
+  h->hist_ws_cap = bytes + bytes / 4;
+  return KR_OK;
+}
+
 static void mat3_diag(double* m, double a, double b, double c) {
   for (int i = 0; i < 9; ++i) m[i] = 0;
   m[0] = a; m[4] = b; m[8] = c;
@@ -185,7 +198,8 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
                          const void* prev_init, hipStream_t s) {
   const size_t slot = (size_t)B * h->params.N * KR_SLOTS;
   T* base = (T*)states;
-  const int wpr = step_waves_per_rod<T>(h, scheme, use_nn, B, 0);  // (one predictor image per wavefront of a rod)
+  // (one predictor image per wavefront of a rod)
+  const int wpr = use_nn ? nn_sim_waves_per_rod<T>(h, scheme, B) : step_waves_per_rod<T>(h, scheme, use_nn, B, 0);
   const int img_w = wpr ? wpr : 1;
   {
     // one launch for all steps when a multiple-shooting kernel with a persistent form applies
@@ -456,6 +470,7 @@ int kr_destroy(kr_handle* h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->pred_buf) (void)hipFree(h->pred_buf);
   if (h->resume_buf) (void)hipFree(h->resume_buf);
+  if (h->hist_ws) (void)hipFree(h->hist_ws);
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   delete h;
   return KR_OK;

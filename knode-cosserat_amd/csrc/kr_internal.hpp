@@ -91,6 +91,8 @@ struct kr_handle {
   int last_overlap = 0;      // the last kr_simulate_batch ran the overlapped kernel
   void* resume_buf = nullptr;  // int32 per rod (SimArgs::resume)
   size_t resume_cap = 0;
+  void* hist_ws = nullptr;     // history records [B][N][12] of the several-wavefront persistent kernel with the MLP on
+  size_t hist_ws_cap = 0;
 };
 
 namespace kr {
@@ -187,6 +189,7 @@ struct SimArgs {
   // exactly there with its full fallback ladder.  nullptr: every rod starts at step 0.
   int32_t* resume = nullptr;
   int residual_test = 1;  // option "residual_test"
+  T* hist_ws = nullptr;   // kr_msw_impl.hpp, MLP on: [B][N][12] history records (global memory instead of LDS)
 };
 
 // returns 1 when the persistent form does not apply
@@ -199,6 +202,14 @@ int launch_mso_sim(kr_handle* h, const SimArgs<T>& a, hipStream_t s);
 int ensure_resume(kr_handle* h, int64_t B);
 template <typename T>
 int prepare_mso_sim(kr_handle* h, int64_t B);
+// kr_mswn_f32.hip / kr_mswn_f64.hip: several wavefronts per rod with the MLP on (persistent form; kr_msw_impl.hpp).
+// nn_sim_waves_per_rod: wavefronts per rod kr_simulate_batch will use for this batch (0: the one-wavefront kernel);
+// launch_msw_nn_sim returns 1 when it does not serve the problem
+template <typename T>
+int nn_sim_waves_per_rod(kr_handle* h, int scheme, int64_t B);
+template <typename T>
+int launch_msw_nn_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s);
+int ensure_hist_ws(kr_handle* h, size_t bytes);
 // kr_sim_f32.hip / kr_sim_f64.hip: the same for the one-wavefront persistent kernel that runs behind it
 template <typename T>
 int prepare_ms_sim(kr_handle* h);

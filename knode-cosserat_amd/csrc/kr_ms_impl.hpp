@@ -1604,6 +1604,10 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
   h->last_waves_per_rod = 1;
   const MlpDev<T>& M = mlpdev<T>(h);
   if (use_nn) {
+    if (const int W = nn_sim_waves_per_rod<T>(h, scheme, a.B)) {  // several wavefronts per rod, MLP on (kr_mswn_*.hip)
+      const int rc = launch_msw_nn_sim<T>(h, W, a, s);
+      if (rc != 1) return rc;
+    }
     // MLP inside the sweeps: the matrix-core evaluator, Euler sweeps and diagonal material matrices only (one
     // more instantiation of the largest kernel per arithmetic type; everything else takes one launch per step)
     if (M.n_layers <= 0 || !M.mfma_ok || h->params.nn_input_history || scheme != KR_EULER || !P.diag) return 1;

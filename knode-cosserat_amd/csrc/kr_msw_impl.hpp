@@ -86,23 +86,34 @@ struct MswLds {
   T* dY;     // [P][19] updates of all unknowns
   T* sp;     // [P][4] p-row terms of every interval
   T* red;    // [W][32] reduction scratch
-  T* Es;     // [W][64][19]
-  T* Lt;     // [W][2][19][MSW_LT_LD]
+  T* Es;     // [W] blocks of wblk elements: end states Es_w [64][19], then the local-map tiles Lt_w [2][19][MSW_LT_LD]
+  size_t wblk;
+  __device__ __forceinline__ T* es(int wave) const { return Es + (size_t)wave * wblk; }
+  __device__ __forceinline__ T* lt(int wave) const { return Es + (size_t)wave * wblk + ((64 * 19 + 3) & ~3); }
 };
+// Block of one wavefront.  With the MLP on it doubles, during a sweep, as the wavefront's scratch of the base + JVP
+// evaluator (mlp_jvp.hpp: both are dead then), so it is at least that large.
+template <typename T>
+__host__ __device__ constexpr size_t msw_wave_block(bool nn) {
+  size_t n = ((64 * 19 + 3) & ~3) + 2 * 19 * MSW_LT_LD;
+  if (nn && n < mj_scratch_elems<T>()) n = mj_scratch_elems<T>();
+  return (n + 3) & ~size_t(3);
+}
+// hist_lds = false: the history records live in global memory (the persistent kernel with the MLP on)
 template <typename T, int W>
-__host__ __device__ inline size_t msw_lds_elems(int N) {
+__host__ __device__ inline size_t msw_lds_elems(int N, bool nn = false, bool hist_lds = true) {
   constexpr int P = MswGeo<W>::P;
   auto r4 = [](size_t n) { return (n + 3) & ~size_t(3); };
-  return r4((size_t)N * HS_LEAN) + r4(P * 19) + r4(CD_SIZE) + 48 + r4(W * 19 * 8) + r4(P * 19) + r4(P * 4) + W * 32 +
-         (size_t)W * r4(64 * 19) + (size_t)W * 2 * 19 * MSW_LT_LD;
+  return (hist_lds ? r4((size_t)N * HS_LEAN) : 0) + r4(P * 19) + r4(CD_SIZE) + 48 + r4(W * 19 * 8) + r4(P * 19) + r4(P * 4) +
+         W * 32 + (size_t)W * msw_wave_block<T>(nn);
 }
 template <typename T, int W>
-__device__ __forceinline__ MswLds<T, W> msw_carve(T* smem, int N) {
+__device__ __forceinline__ MswLds<T, W> msw_carve(T* smem, int N, bool nn = false, bool hist_lds = true) {
   constexpr int P = MswGeo<W>::P;
   auto r4 = [](size_t n) { return (n + 3) & ~size_t(3); };
   MswLds<T, W> L;
-  L.hist = smem;
-  L.Xs = L.hist + r4((size_t)N * HS_LEAN);
+  L.hist = hist_lds ? smem : nullptr;
+  L.Xs = smem + (hist_lds ? r4((size_t)N * HS_LEAN) : 0);
   L.cold = L.Xs + r4(P * 19);
   L.Tm = L.cold + r4(CD_SIZE);
   L.Xbd = L.Tm + 48;
@@ -110,8 +121,44 @@ __device__ __forceinline__ MswLds<T, W> msw_carve(T* smem, int N) {
   L.sp = L.dY + r4(P * 19);
   L.red = L.sp + r4(P * 4);
   L.Es = L.red + W * 32;
-  L.Lt = L.Es + (size_t)W * r4(64 * 19);
+  L.wblk = msw_wave_block<T>(nn);
   return L;
+}
+
+// the MLP inside a sweep (instantiations with NN; unused otherwise)
+template <typename T>
+struct MswNn {
+  const MlpDev<T>* M = nullptr;
+  T* tile = nullptr;   // scratch of this wavefront's evaluator calls: its Es / Lt block
+  V3<T> tf{T(0), T(0), T(0)};  // tendon force sum, an input of the network (cosserat_ode.py:171-178)
+  NnRole role;
+};
+// Padding slots of a record in the instantiations with the MLP on: a zero the optimiser cannot merge with the other
+// zeros of the kernel.  As a shared constant, hipcc 7.2 kept (u.z, 0.0) in a register tuple across the whole kernel and
+// spilled it inside a whole-wave-mode bracket it had opened for its SGPR-spill registers - the lanes that were idle
+// where the tuple was built put garbage into the slot, and the next user under a full exec mask (a zero address
+// offset) faulted.  tools/wwm_spill_scan.py looks for that pattern in the assembly.
+template <typename T, bool NN>
+__device__ __forceinline__ void msw_record_pad(T (&rec)[KR_SLOTS]) {
+  if constexpr (NN) {
+    T z;
+    if constexpr (sizeof(T) == 8) asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+    else asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    rec[25] = z; rec[26] = z; rec[27] = z;
+  }
+}
+template <typename T, int W>
+__device__ __forceinline__ MswNn<T> msw_nn_ctx(const MlpDev<T>& M, const MswLds<T, W>& L, const MswRole& R, int lane, V3<T> tf) {
+  MswNn<T> nn;
+  nn.M = &M;
+  nn.tile = L.es(R.w);
+  nn.tf = tf;
+  nn.role.iv = R.ivl; nn.role.col = R.col; nn.role.idle = R.idle; nn.role.jvp = true;
+  // the dx rows nobody owns are zeroed by the lanes without a column: rows 6..15 of sample tile 0 on wavefront 0 (its
+  // first interval has 6 columns), sample tile 3 on the others (three intervals)
+  if (R.w == 0) nn.role.zrow = 6 + (R.idle ? 4 + (lane - 58) : R.ivl);
+  else nn.role.zrow = 48 + (R.idle ? 3 + (lane - 51) : R.ivl);
+  return nn;
 }
 
 // av, au of a grid point from its raw history (see RodHist)
@@ -407,8 +454,8 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
   constexpr int P = MswGeo<W>::P;
   const int wave = R.w;
   T* Xs = L.Xs;
-  T* Es = L.Es + (size_t)wave * ((64 * 19 + 3) & ~3);
-  T* Lt = L.Lt + (size_t)wave * 2 * 19 * MSW_LT_LD;
+  T* Es = L.es(wave);
+  T* Lt = L.lt(wave);
   float* redf = reinterpret_cast<float*>(L.red);
   const int col = R.col;
   const bool idle = R.idle;
@@ -729,9 +776,11 @@ __device__ __forceinline__ void msw_apply(const MswLds<T, W>& L, const MswRole& 
 }
 
 // ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
-template <typename T, bool DIAG, int W>
+// hist: the history records [N][HS_LEAN] (LDS, or global memory in the persistent kernel with the MLP on)
+template <typename T, bool DIAG, int W, bool NN = false>
 __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
-                                          V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps) {
+                                          V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps,
+                                          const T* hist, const MswNn<T>& nn) {
   constexpr int P = MswGeo<W>::P;
   const int N = Pc.N;
   const int wave = R.w;
@@ -740,8 +789,8 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
   KR_STAMP(tq);
 #endif
   T* Xs = L.Xs;
-  T* Es = L.Es + (size_t)wave * ((64 * 19 + 3) & ~3);
-  T* Lt = L.Lt + (size_t)wave * 2 * 19 * MSW_LT_LD;
+  T* Es = L.es(wave);
+  T* Lt = L.lt(wave);
   float* redf = reinterpret_cast<float*>(L.red);
   const int iv = R.iv, col = R.col;
   const bool idle = R.idle;
@@ -769,16 +818,23 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 
     // ---- sweep over this lane's sub-interval (explicit Euler, cosserat_ode.py:198-201) ------------------
     T hv[HS_LEAN];
-    load_hist_vec<T, HS_LEAN>(L.hist + (size_t)R.s_i * HS_LEAN, hv);
-    auto point = [&](auto store_tag, int j) __attribute__((always_inline)) {
+    load_hist_vec<T, HS_LEAN>(hist + (size_t)R.s_i * HS_LEAN, hv);
+    auto point = [&](auto store_tag, int j, bool live) __attribute__((always_inline)) {
       constexpr bool STORE = decltype(store_tag)::value;
       RodState<T> k1;
       V3<T> v, u;
       ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
+#ifndef KR_MSWN_NO_EVAL
+      if constexpr (NN)  // every wavefront evaluates the network for its own lanes (cosserat_ode.py:169-184)
+#else
+      if constexpr (false)
+#endif
+        nn_correct<T, HS_LEAN>(*nn.M, nullptr, nullptr, 0, nn.tile, lane, nn.role, y, hv, nn.tf, k1, v, u);
       if constexpr (STORE) {
-        if (st) {
+        if (st && live) {
           T rec[KR_SLOTS];
           record_from(y, v, u, rec);
+          msw_record_pad<T, NN>(rec);
           store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
           if (S.lead12) {
             T lead[12];
@@ -788,20 +844,33 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
           }
         }
       }
-      load_hist_vec<T, HS_LEAN>(L.hist + (size_t)(j + 1) * HS_LEAN, hv);
+      load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 1) * HS_LEAN, hv);
       y = state_axpy(y, Pc.ds, k1);
     };
-    if (storing || flush) {
-      for (int t = 0; t < R.sbase; ++t) point(std::true_type{}, R.s_i + t);
-      if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase);
+    if constexpr (NN) {
+      // with the MLP on every lane must reach the wavefront-wide matrix-core call: lanes past the end of their
+      // (shorter) interval keep running on the last grid point and do not commit (kr_ms_impl.hpp, ms_newton)
+      const int lmax = R.sbase + (R.g0 < (N - 1) % P ? 1 : 0);  // (the long intervals come first)
+      for (int t = 0; t < lmax; ++t) {
+        const bool live = t < R.len_i;
+        const int j = live ? R.s_i + t : R.s_i + R.len_i - 1;
+        const RodState<T> y_in = y;
+        if (storing || flush) point(std::true_type{}, j, live);  // (wave-uniform choice)
+        else point(std::false_type{}, j, true);
+        if (!live) y = y_in;
+      }
+    } else if (storing || flush) {
+      for (int t = 0; t < R.sbase; ++t) point(std::true_type{}, R.s_i + t, true);
+      if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase, true);
     } else {
 #pragma unroll KR_MS_UNROLL
-      for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t);
-      if (R.len_i > R.sbase) point(std::false_type{}, R.s_i + R.sbase);
+      for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t, true);
+      if (R.len_i > R.sbase) point(std::false_type{}, R.s_i + R.sbase, true);
     }
     if (st && iv == P - 1) {
       T rec[KR_SLOTS];
       record_from(y, S.vlast, S.ulast, rec);
+      msw_record_pad<T, NN>(rec);
       store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
       if (S.lead12) {
         T lead[12];
@@ -820,7 +889,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 
     // ---- residual test of a storing sweep that follows a small update (kr_ms_impl.hpp, ms_newton) ------------
     float res_local = 0.f;
-    if (S.quick_ok && storing && amp > 0.f && dn_prev > T(0) && dn_prev <= T(1e-2)) {
+    if (!NN && S.quick_ok && storing && amp > 0.f && dn_prev > T(0) && dn_prev <= T(1e-2)) {  // (MLP on: approximate Jacobian, ratio not audited)
       {
         T er[19];
         state_to_rows(y, er);
@@ -908,9 +977,9 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 // unknowns.  Called by wavefront 0 only; the other wavefronts wait at the workgroup barrier that follows.  With it the
 // status of a hard step no longer depends on which kernel the batch size selects.
 // ---------------------------------------------------------------------------
-template <typename T, bool DIAG, int W>
+template <typename T, bool DIAG, int W, bool NN = false>
 __device__ __forceinline__ int msw_ss_damped(const RodConst<T>& Pc, const MswLds<T, W>& L, int lane, V3<T> fconst,
-                                             MsSolveArgs<T>& S, int& it) {
+                                             MsSolveArgs<T>& S, int& it, const T* hist, const MswNn<T>& nn) {
   constexpr int P = MswGeo<W>::P;
   const int N = Pc.N;
   const int col = lane < 7 ? lane : 0;  // lanes 7.. duplicate the unperturbed column and store nothing
@@ -922,7 +991,10 @@ __device__ __forceinline__ int msw_ss_damped(const RodConst<T>& Pc, const MswLds
   int status = KR_ST_MAXIT;
   const int maxit = 8 * S.maxit;
   it = 0;
-  T* Rx = L.Es;  // [7][6] residuals of the seven columns (Es of wavefront 0 is free between sweeps)
+  // [7][6] residuals of the seven columns: Es of wavefront 0 is free between sweeps - with the MLP on it is the
+  // evaluator's scratch (lanes 0..6 are the unperturbed lane and six columns of "interval 0" there too, the other
+  // lanes copies of the unperturbed one: the roles of the multiple-shooting sweep fit as they are), so dY serves
+  T* Rx = NN ? L.dY : L.Es;
   while (true) {
     T hs[6];
     RodState<T> y;
@@ -944,13 +1016,15 @@ __device__ __forceinline__ int msw_ss_damped(const RodConst<T>& Pc, const MswLds
     int gnext = 1, jnext = msw_start(1, N, P);  // interval starts passed on the way (for L.Xs)
     for (int j = 0; j < N - 1; ++j) {
       T hv[HS_LEAN];
-      load_hist_vec<T, HS_LEAN>(L.hist + (size_t)j * HS_LEAN, hv);
+      load_hist_vec<T, HS_LEAN>(hist + (size_t)j * HS_LEAN, hv);
       RodState<T> k1;
       V3<T> v, u;
       ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
+      if constexpr (NN) nn_correct<T, HS_LEAN>(*nn.M, nullptr, nullptr, 0, nn.tile, lane, nn.role, y, hv, nn.tf, k1, v, u);
       if (lane == 0) {
         T rec[KR_SLOTS];
         record_from(y, v, u, rec);
+        msw_record_pad<T, NN>(rec);
         if (S.out_rod) store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
         if (S.lead12) {
           T lead[12];
@@ -971,6 +1045,7 @@ __device__ __forceinline__ int msw_ss_damped(const RodConst<T>& Pc, const MswLds
     if (lane == 0) {
       T rec[KR_SLOTS];
       record_from(y, S.vlast, S.ulast, rec);
+      msw_record_pad<T, NN>(rec);
       if (S.out_rod) store_record(S.out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
       if (S.lead12) {
         T lead[12];
@@ -1091,6 +1166,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
   const int ne = R.K * 19;
   T* Xl = L.Xs + R.g0 * 19;
   int it, status;
+  const MswNn<T> nn;  // (MLP off in this kernel)
 #ifdef KR_MS_STAMPS
   KR_STAMP_ADD(stamps.prep, tp);
 #endif
@@ -1106,7 +1182,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       wave_sync();
       if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];  // caller's guess (knode.py:67,89)
       __syncthreads();
-      status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
+      status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps, L.hist, nn);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
@@ -1116,7 +1192,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       if (wave == 0) {
         if (lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];
         wave_sync();
-        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it);
+        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it, L.hist, nn);
         if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
       }
       __syncthreads();
@@ -1147,13 +1223,13 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       Xl[e] = g;
     }
     __syncthreads();
-    status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
+    status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps, L.hist, nn);
     if (status != KR_ST_CONVERGED) {  // damped single shooting from the caller's guess
       __syncthreads();
       if (wave == 0) {
         if (lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];
         wave_sync();
-        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it);
+        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it, L.hist, nn);
         if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
       }
       __syncthreads();
@@ -1192,11 +1268,18 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
 
 // ---- all steps of kr_simulate_batch in one launch: the same solver, the leading slots of the two newest states kept in
 // LDS (the history records of the next step never touch HBM), the predictors in registers ---------------------------
+// MLP off: history records and the leading slots of the two newest states in LDS.  MLP on (NN): both in global memory
+// (the history in a workspace [B][N][12] this workgroup writes and reads, the states where they are, in A.states) - a
+// grid point then costs ~20 k cycles of network evaluation, against which an L2-resident 96-byte read is nothing, and
+// without them four rods fit the LDS of a CU in fp64 too: 1024 rods run at two wavefronts per SIMD, each sweeping a
+// chain half as long, and the waits of one wavefront's evaluator chain are filled by the other's.
 template <typename T, int W>
-__host__ __device__ inline size_t msw_sim_lds_elems(int N) { return msw_lds_elems<T, W>(N) + (size_t)2 * N * 12; }
+__host__ __device__ inline size_t msw_sim_lds_elems(int N, bool nn = false) {
+  return nn ? msw_lds_elems<T, W>(N, true, false) : msw_lds_elems<T, W>(N) + (size_t)2 * N * 12;
+}
 
-template <typename T, bool DIAG, int W>
-__global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A) {
+template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1>
+__global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A, const MlpDev<T> M) {
   constexpr int P = MswGeo<W>::P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = Pc.N;
@@ -1205,20 +1288,23 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
   const int64_t rod = blockIdx.x;
   const size_t rod_elems = (size_t)N * KR_SLOTS;
   T* smem = reinterpret_cast<T*>(smem_raw);
-  const MswLds<T, W> L = msw_carve<T, W>(smem, N);
-  T* lead0 = smem + msw_lds_elems<T, W>(N);  // [2][N][12]: newest state / the one before (roles alternate)
+  const MswLds<T, W> L = msw_carve<T, W>(smem, N, NN, !NN);
+  T* lead0 = NN ? nullptr : smem + msw_lds_elems<T, W>(N);  // [2][N][12]: newest state / the one before (roles alternate)
+  const T* hist = NN ? A.hist_ws + (size_t)rod * N * HS_LEAN : L.hist;
   const int lsz = N * 12;
   const MswRole R = msw_role<W>(wave, lane, N);
   MsStamps stamps;
   if (wave == 0) ms_cold_fill<T>(Pc, L.cold, lane);
   const T* s0 = A.states + rod * rod_elems;
   const T* sp = A.prev_init ? A.prev_init + rod * rod_elems : s0;
-  for (int j = threadIdx.x; j < N; j += WAVE * W) {
-    T cv[12], pv[12];
-    load_hist_vec<T, 12>(s0 + (size_t)j * KR_SLOTS, cv);
-    load_hist_vec<T, 12>(sp + (size_t)j * KR_SLOTS, pv);
-    store_vec<T, 12>(lead0 + (size_t)j * 12, cv);
-    store_vec<T, 12>(lead0 + lsz + (size_t)j * 12, pv);
+  if constexpr (!NN) {
+    for (int j = threadIdx.x; j < N; j += WAVE * W) {
+      T cv[12], pv[12];
+      load_hist_vec<T, 12>(s0 + (size_t)j * KR_SLOTS, cv);
+      load_hist_vec<T, 12>(sp + (size_t)j * KR_SLOTS, pv);
+      store_vec<T, 12>(lead0 + (size_t)j * 12, cv);
+      store_vec<T, 12>(lead0 + lsz + (size_t)j * 12, pv);
+    }
   }
   const int ne = R.K * 19;
   T* Xl = L.Xs + R.g0 * 19;
@@ -1231,23 +1317,44 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
   S.kappa = Q.kappa;
   T Gguess = (wave == 0 && lane < 6) ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
+  MswNn<T> nn;
   __syncthreads();
   for (int64_t t = 0; t < A.T_steps; ++t) {
-    const T* cur = lead0 + (int)(t & 1) * lsz;        // leading slots of the state at time level t
-    T* prv = lead0 + (int)((t + 1) & 1) * lsz;        // ... of level t - 1; the storing sweep overwrites them with level t + 1
-    // BDF2 history (knode.py:74-75), raw terms only
-    for (int j = threadIdx.x; j < N; j += WAVE * W) {
-      T cv[12], pv[12], hv[12];
-      load_hist_vec<T, 12>(cur + (size_t)j * 12, cv);
-      load_hist_vec<T, 12>(prv + (size_t)j * 12, pv);
+    T* prv = nullptr;
+    if constexpr (NN) {
+      // BDF2 history (knode.py:74-75) from the two newest states in A.states (this workgroup wrote them: visible after
+      // the barrier that ended the step), into the rod's rows of the workspace
+      const T* rc = A.states + (A.ring ? t % 3 : t) * A.slot_elems + rod * rod_elems;
+      const T* rp = t > 0 ? A.states + (A.ring ? (t - 1) % 3 : t - 1) * A.slot_elems + rod * rod_elems : sp;
+      T* hw = A.hist_ws + (size_t)rod * N * HS_LEAN;
+      for (int j = threadIdx.x; j < N; j += WAVE * W) {
+        T cv[12], pv[12], hv[12];
+        load_hist_vec<T, 12>(rc + (size_t)j * KR_SLOTS, cv);
+        load_hist_vec<T, 12>(rp + (size_t)j * KR_SLOTS, pv);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[k] + A.hc2 * pv[k];
-      store_vec<T, 12>(L.hist + (size_t)j * HS_LEAN, hv);
-    }
-    {  // z of the last grid point is never touched by a sweep
-      const T* cl = cur + (size_t)(N - 1) * 12;
+        for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[k] + A.hc2 * pv[k];
+        store_vec<T, 12>(hw + (size_t)j * HS_LEAN, hv);
+      }
+      const T* cl = rc + (size_t)(N - 1) * KR_SLOTS;  // z of the last grid point is never touched by a sweep
       S.vlast = {cl[6], cl[7], cl[8]};
       S.ulast = {cl[9], cl[10], cl[11]};
+    } else {
+      const T* cur = lead0 + (int)(t & 1) * lsz;        // leading slots of the state at time level t
+      prv = lead0 + (int)((t + 1) & 1) * lsz;           // ... of level t - 1; the storing sweep overwrites them with level t + 1
+      // BDF2 history (knode.py:74-75), raw terms only
+      for (int j = threadIdx.x; j < N; j += WAVE * W) {
+        T cv[12], pv[12], hv[12];
+        load_hist_vec<T, 12>(cur + (size_t)j * 12, cv);
+        load_hist_vec<T, 12>(prv + (size_t)j * 12, pv);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[k] + A.hc2 * pv[k];
+        store_vec<T, 12>(L.hist + (size_t)j * HS_LEAN, hv);
+      }
+      {  // z of the last grid point is never touched by a sweep
+        const T* cl = cur + (size_t)(N - 1) * 12;
+        S.vlast = {cl[6], cl[7], cl[8]};
+        S.ulast = {cl[9], cl[10], cl[11]};
+      }
     }
     __syncthreads();
     V3<T> fconst;
@@ -1261,6 +1368,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
         tf.z += tt * L.cold[CD_TDIRS + k * 3 + 2];
       }
       fconst = {L.cold[CD_RHOAG] + tf.x, L.cold[CD_RHOAG + 1] + tf.y, L.cold[CD_RHOAG + 2] + tf.z};
+      if constexpr (NN) nn = msw_nn_ctx<T, W>(M, L, R, lane, tf);
     }
     const int64_t inx = A.ring ? (t + 1) % 3 : t + 1;
     S.out_rod = A.states + inx * A.slot_elems + rod * rod_elems;
@@ -1273,7 +1381,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
       wave_sync();
       if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
       __syncthreads();
-      status = msw_newton<T, DIAG, W>(Pc, L, R, lane, fconst, S, it, stamps);
+      status = msw_newton<T, DIAG, W, NN>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
@@ -1283,7 +1391,7 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
       if (wave == 0) {
         if (lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;
         wave_sync();
-        status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it);
+        status = msw_ss_damped<T, DIAG, W, NN>(Pc, L, lane, fconst, S, it, hist, nn);
         if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
       }
       __syncthreads();
@@ -1303,16 +1411,16 @@ __global__ __launch_bounds__(WAVE * W) void msw_sim_kernel(const RodConst<T> Pc,
   }
 }
 
-template <typename T, bool DIAG, int W>
-static int launch_msw_sim_inst(const RodConst<T>& P, const SimArgs<T>& a, hipStream_t s) {
-  auto kern = msw_sim_kernel<T, DIAG, W>;
-  const size_t smem = sizeof(T) * msw_sim_lds_elems<T, W>(P.N);
+template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1>
+static int launch_msw_sim_inst(const RodConst<T>& P, const MlpDev<T>& M, const SimArgs<T>& a, hipStream_t s) {
+  auto kern = msw_sim_kernel<T, DIAG, W, NN, OCC>;
+  const size_t smem = sizeof(T) * msw_sim_lds_elems<T, W>(P.N, NN);
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     configured = smem;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * W), smem, s, P, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * W), smem, s, P, a, M);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }
@@ -1325,8 +1433,9 @@ static int launch_msw_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t 
   const int64_t per_cu = (int64_t)((size_t)h->lds_limit / bytes);
   if (a.B > 256 * per_cu) return 1;  // (a second round of workgroups would wait for the first to finish all steps)
   h->last_waves_per_rod = W;
-  if (W == 2) return P.diag ? launch_msw_sim_inst<T, true, 2>(P, a, s) : launch_msw_sim_inst<T, false, 2>(P, a, s);
-  return P.diag ? launch_msw_sim_inst<T, true, 4>(P, a, s) : launch_msw_sim_inst<T, false, 4>(P, a, s);
+  const MlpDev<T>& M = mlpdev<T>(h);
+  if (W == 2) return P.diag ? launch_msw_sim_inst<T, true, 2>(P, M, a, s) : launch_msw_sim_inst<T, false, 2>(P, M, a, s);
+  return P.diag ? launch_msw_sim_inst<T, true, 4>(P, M, a, s) : launch_msw_sim_inst<T, false, 4>(P, M, a, s);
 }
 
 template <typename T, int W>

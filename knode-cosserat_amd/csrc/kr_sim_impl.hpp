@@ -237,6 +237,7 @@ __device__ __forceinline__ void solve6(T (&a)[6][7], T (&x)[6]) {
 struct NnRole {
   int iv = 0, col = 0;
   bool idle = false, jvp = false;
+  int zrow = -1;  // dx row a lane without a column zeroes (-1: the layout of the one-wavefront kernels)
 };
 template <typename T, int HS>
 __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB, int stride, T* tile, int lane,
@@ -252,7 +253,7 @@ __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB,
       x[19] = v.x; x[20] = v.y; x[21] = v.z; x[22] = u.x; x[23] = u.y; x[24] = u.z;
       x[25] = tf.x; x[26] = tf.y; x[27] = tf.z;
       T d[25];
-      if (role.jvp && M.jvp_ok) mlp_jvp_eval<T>(M, x, tile, lane, role.iv, role.col, role.idle, d);  // wave-uniform choice
+      if (role.jvp && M.jvp_ok) mlp_jvp_eval<T>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d);  // wave-uniform choice
       else mlp_mfma_eval<T>(M, x, tile, lane, d);
       T yr2[19];
       state_to_rows(ys, yr2);

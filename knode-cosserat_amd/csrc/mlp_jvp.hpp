@@ -374,11 +374,13 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
   mm_wave_sync();
 }
 
-// Per-lane wrapper.  iv / col: the lane's role (sub-interval, 0 = unperturbed); idle lanes pass col = 0 and a
-// copy of their interval's state.  x in, NN(x) (base lanes) or NN(x_base) + J dx (the others) out.
+// Per-lane wrapper.  iv / col: the lane's role (sub-interval of the wavefront 0..3, 0 = unperturbed); idle lanes pass
+// col = 0 and a copy of their interval's state.  zrow: the dx row a lane without a column zeroes (the rows no column
+// owns: every sample tile has 16, an interval 6 or 16 columns; -1 = lane layout 7 + 3 x 17 of kr_ms_impl.hpp).
+// x in, NN(x) (base lanes) or NN(x_base) + J dx (the others) out.
 template <typename T>
 __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
-                                             bool idle, T (&out)[25]) {
+                                             bool idle, int zrow, T (&out)[25]) {
   using V = typename MjVec<T>::type;
   constexpr int n = MjVec<T>::n;
   T* xb = scratch;
@@ -395,33 +397,33 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
     }
   }
   mm_wave_sync();
-  // dx row of this lane; the 10 lanes without a column (4 base, 6 idle) zero the 10 unused rows of sample tile 0
+  // dx row of this lane; the lanes without a column (base and idle ones) zero the rows no column owns.  Written without
+  // a branch on the lane's role: the wrapper sits in the middle of the register-starved sweep kernels, and spill code
+  // inside divergent control flow there has produced wrong reloads (hipcc 7.2, fp64, kr_msw_impl.hpp with the MLP on).
   {
-    int row;
+    const bool has = col > 0;
+    const int row = has ? 16 * iv + col - 1 : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
     float d[MM_IN];
-    if (col > 0) {
-      row = 16 * iv + col - 1;
-      const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);
+    const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);
 #pragma unroll
-      for (int k = 0; k < MM_IN / n; ++k) {
-        const V v = b[k];
+    for (int k = 0; k < MM_IN / n; ++k) {
+      const V v = b[k];
 #pragma unroll
-        for (int e = 0; e < n; ++e) d[k * n + e] = (float)(x[k * n + e] - v[e]);
-      }
-    } else {
-      row = 6 + (idle ? 4 + (lane - 58) : iv);
-#pragma unroll
-      for (int k = 0; k < MM_IN; ++k) d[k] = 0.f;
+      for (int e = 0; e < n; ++e) d[k * n + e] = has ? (float)(x[k * n + e] - v[e]) : 0.f;
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4* dst = reinterpret_cast<u32x4*>(dreg + (size_t)row * (MJ_DX_LD * 2));
+    // the padding columns 28..31: a zero the optimiser cannot share with other zeros of the kernel (as a common
+    // constant it was kept in a register tuple across the whole kernel, spilled, and that spill is what went wrong)
+    unsigned zpad;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zpad));
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       u32x4 p;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = 8 * v + 2 * e;
-        p[e] = k + 1 < MM_IN ? pack_bf2(d[k < MM_IN ? k : 0], d[k + 1 < MM_IN ? k + 1 : 0]) : 0u;
+        p[e] = k + 1 < MM_IN ? pack_bf2(d[k < MM_IN ? k : 0], d[k + 1 < MM_IN ? k + 1 : 0]) : zpad;
       }
       dst[v] = p;
     }
@@ -445,14 +447,16 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
       for (int e = 0; e < n; ++e)
         if (k * n + e < 25) out[k * n + e] = v[e];
     }
-    if (col > 0) {
-      const f32x4* dr = reinterpret_cast<const f32x4*>(dreg + (size_t)(16 * iv + col - 1) * (MJ_DOUT_LD * 4));
+    {  // (no branch on the role here either: a lane without a column adds its zero row)
+      const int row = col > 0 ? 16 * iv + col - 1 : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
+      const bool has = col > 0;  // (a select, not a product: the rows of a missing interval may hold NaN)
+      const f32x4* dr = reinterpret_cast<const f32x4*>(dreg + (size_t)row * (MJ_DOUT_LD * 4));
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const f32x4 v = dr[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (4 * k + e < 25) out[4 * k + e] += (T)v[e];
+          if (4 * k + e < 25) out[4 * k + e] += has ? (T)v[e] : T(0);
       }
     }
   }

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k(MlpDev<T> M, T* out, unsigned long long
   __builtin_amdgcn_s_waitcnt(0xC07F);
   for (int it = 0; it < iters; ++it) {
     T d[25];
-    mlp_jvp_eval<T>(M, x, scratch, lane, iv, col, idle, d);
+    mlp_jvp_eval<T>(M, x, scratch, lane, iv, col, idle, -1, d);
     for (int c = 0; c < 25; ++c) o[c] += d[c];
     x[0] += d[0] * T(1e-9);
   }
