@@ -382,7 +382,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       constexpr bool STORE = decltype(store_tag)::value;
       RodState<T> k1;
       V3<T> v, u;
-      eval_point<T, DIAG, NN, HS>(Pc, M, C, y, hv, k1, v, u);
+      eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, y, hv, k1, v, u);
       if constexpr (STORE) {
         if (st && live) {
           T rec[KR_SLOTS];
@@ -407,11 +407,11 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
         RodState<T> k2, k3, k4;
         V3<T> v2, u2;
         RodState<T> ya = state_axpy(y, Pc.ds * T(0.5), k1);
-        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k2, v2, u2);
+        eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, ya, hm, k2, v2, u2);
         ya = state_axpy(y, Pc.ds * T(0.5), k2);
-        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k3, v2, u2);
+        eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, ya, hm, k3, v2, u2);
         ya = state_axpy(y, Pc.ds, k3);
-        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hn, k4, v2, u2);
+        eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, ya, hn, k4, v2, u2);
         RodState<T> ksum = state_axpy(k1, T(2), k2);
         ksum = state_axpy(ksum, T(2), k3);
         ksum = state_axpy(ksum, T(1), k4);
@@ -882,7 +882,7 @@ __device__ __forceinline__ int ss_newton_damped(const RodConst<T>& Pc, const Mlp
     for (int j = 0; j < N - 1; ++j) {
       RodState<T> k1;
       V3<T> v, u;
-      eval_point<T, DIAG, NN, HS>(Pc, M, C, y, hv, k1, v, u);
+      eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, y, hv, k1, v, u);
       if (lane == 0) {
         T rec[KR_SLOTS];
         record_from(y, v, u, rec);
@@ -912,11 +912,11 @@ __device__ __forceinline__ int ss_newton_damped(const RodConst<T>& Pc, const Mlp
         RodState<T> k2, k3, k4;
         V3<T> v2, u2;
         RodState<T> ya = state_axpy(y, Pc.ds * T(0.5), k1);
-        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k2, v2, u2);
+        eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, ya, hm, k2, v2, u2);
         ya = state_axpy(y, Pc.ds * T(0.5), k2);
-        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hm, k3, v2, u2);
+        eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, ya, hm, k3, v2, u2);
         ya = state_axpy(y, Pc.ds, k3);
-        eval_point<T, DIAG, NN, HS>(Pc, M, C, ya, hn, k4, v2, u2);
+        eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, ya, hn, k4, v2, u2);
         RodState<T> ksum = state_axpy(k1, T(2), k2);
         ksum = state_axpy(ksum, T(2), k3);
         ksum = state_axpy(ksum, T(1), k4);
@@ -1610,7 +1610,8 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
     }
     // MLP inside the sweeps: the matrix-core evaluator, Euler sweeps and diagonal material matrices only (one
     // more instantiation of the largest kernel per arithmetic type; everything else takes one launch per step)
-    if (M.n_layers <= 0 || !M.mfma_ok || h->params.nn_input_history || scheme != KR_EULER || !P.diag) return 1;
+    // (the persistent kernel carries the base + JVP evaluator only: a network it does not serve takes one launch per step)
+    if (M.n_layers <= 0 || !M.mfma_ok || !M.jvp_ok || h->params.nn_input_history || scheme != KR_EULER || !P.diag) return 1;
     if (P.N - 1 < 2 * MS_P || P.N > MS_NPL * WAVE) return 1;
     if (ms_lds_bytes<T, hs_phys<T>()>(P.N, true, true) > (size_t)h->lds_limit) return 1;
     if (h->ms_mode != 1 && a.B > (int64_t)h->ms_batch_limit) return 1;

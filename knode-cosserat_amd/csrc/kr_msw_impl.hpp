@@ -777,7 +777,7 @@ __device__ __forceinline__ void msw_apply(const MswLds<T, W>& L, const MswRole& 
 
 // ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
 // hist: the history records [N][HS_LEAN] (LDS, or global memory in the persistent kernel with the MLP on)
-template <typename T, bool DIAG, int W, bool NN = false>
+template <typename T, bool DIAG, int W, bool NN = false, int EV = 0>
 __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
                                           V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps,
                                           const T* hist, const MswNn<T>& nn) {
@@ -829,7 +829,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 #else
       if constexpr (false)
 #endif
-        nn_correct<T, HS_LEAN>(*nn.M, nullptr, nullptr, 0, nn.tile, lane, nn.role, y, hv, nn.tf, k1, v, u);
+        nn_correct<T, HS_LEAN, EV, true>(*nn.M, nullptr, nullptr, 0, nn.tile, lane, nn.role, y, hv, nn.tf, k1, v, u);
       if constexpr (STORE) {
         if (st && live) {
           T rec[KR_SLOTS];
@@ -977,7 +977,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 // unknowns.  Called by wavefront 0 only; the other wavefronts wait at the workgroup barrier that follows.  With it the
 // status of a hard step no longer depends on which kernel the batch size selects.
 // ---------------------------------------------------------------------------
-template <typename T, bool DIAG, int W, bool NN = false>
+template <typename T, bool DIAG, int W, bool NN = false, int EV = 0>
 __device__ __forceinline__ int msw_ss_damped(const RodConst<T>& Pc, const MswLds<T, W>& L, int lane, V3<T> fconst,
                                              MsSolveArgs<T>& S, int& it, const T* hist, const MswNn<T>& nn) {
   constexpr int P = MswGeo<W>::P;
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ int msw_ss_damped(const RodConst<T>& Pc, const MswLds
       RodState<T> k1;
       V3<T> v, u;
       ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
-      if constexpr (NN) nn_correct<T, HS_LEAN>(*nn.M, nullptr, nullptr, 0, nn.tile, lane, nn.role, y, hv, nn.tf, k1, v, u);
+      if constexpr (NN) nn_correct<T, HS_LEAN, EV, true>(*nn.M, nullptr, nullptr, 0, nn.tile, lane, nn.role, y, hv, nn.tf, k1, v, u);
       if (lane == 0) {
         T rec[KR_SLOTS];
         record_from(y, v, u, rec);
@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       wave_sync();
       if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
       __syncthreads();
-      status = msw_newton<T, DIAG, W, NN>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
+      status = msw_newton<T, DIAG, W, NN, OCC - 1>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       if (wave == 0) {
         if (lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;
         wave_sync();
-        status = msw_ss_damped<T, DIAG, W, NN>(Pc, L, lane, fconst, S, it, hist, nn);
+        status = msw_ss_damped<T, DIAG, W, NN, OCC - 1>(Pc, L, lane, fconst, S, it, hist, nn);
         if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
       }
       __syncthreads();

@@ -17,6 +17,11 @@ template <typename T>
 static bool msw_nn_fits(kr_handle* h, int W, int64_t B) {
   const RodConst<T>& P = consts<T>(h);
   if (P.N - 1 < 2 * (4 + 3 * (W - 1))) return false;
+  // One wavefront per SIMD at most.  The kernel and its evaluator use all 512 registers of a SIMD lane; instantiations
+  // limited to 256 (two wavefronts per SIMD, which B = 1024 would need) were built and measured: everything live in
+  // the sweep is then spilled around every evaluator call and the scratch traffic of eight wavefronts per CU makes a
+  // step 1.9 x SLOWER than one wavefront per rod (fp64 1.88 against 1.00 ms, fp32 1.01 against 0.57 ms at B = 1024).
+  if (B * W > 1024) return false;
   const size_t bytes = sizeof(T) * (W == 2 ? msw_sim_lds_elems<T, 2>(P.N, true) : msw_sim_lds_elems<T, 4>(P.N, true));
   if (bytes > (size_t)h->lds_limit) return false;
   // every rod resident at once (a second round of workgroups would wait for the first to finish all its steps)
@@ -32,10 +37,8 @@ int nn_sim_waves_per_rod(kr_handle* h, int scheme, int64_t B) {
   if (h->waves_per_rod == 1) return 0;
   if (h->waves_per_rod == 2) return msw_nn_fits<T>(h, 2, B) ? 2 : 0;
   if (h->waves_per_rod == 4) return msw_nn_fits<T>(h, 4, B) ? 4 : 0;
-  // auto: up to two wavefronts per SIMD (the evaluator chain is latency bound; a third wavefront finds the vector and
-  // matrix pipes taken)
-  if (B * 4 <= 2048 && msw_nn_fits<T>(h, 4, B)) return 4;
-  if (B * 2 <= 2048 && msw_nn_fits<T>(h, 2, B)) return 2;
+  if (B * 4 <= 1024 && msw_nn_fits<T>(h, 4, B)) return 4;
+  if (B * 2 <= 1024 && msw_nn_fits<T>(h, 2, B)) return 2;
   return 0;
 }
 
@@ -49,9 +52,6 @@ int launch_msw_nn_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s) {
   SimArgs<T> a2 = a;
   a2.hist_ws = static_cast<T*>(h->hist_ws);
   h->last_waves_per_rod = W;
-  // more wavefronts than SIMDs: the instantiation limited to 256 registers, so that two fit a SIMD
-  if (a.B * W > 1024)
-    return W == 2 ? launch_msw_sim_inst<T, true, 2, true, 2>(P, M, a2, s) : launch_msw_sim_inst<T, true, 4, true, 2>(P, M, a2, s);
   return W == 2 ? launch_msw_sim_inst<T, true, 2, true>(P, M, a2, s) : launch_msw_sim_inst<T, true, 4, true>(P, M, a2, s);
 }
 

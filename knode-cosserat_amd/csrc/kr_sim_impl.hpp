@@ -239,22 +239,28 @@ struct NnRole {
   bool idle = false, jvp = false;
   int zrow = -1;  // dx row a lane without a column zeroes (-1: the layout of the one-wavefront kernels)
 };
-template <typename T, int HS>
+// JVP_ONLY: the caller guarantees M.mfma_ok && M.jvp_ok and a lane role (kr_msw_impl.hpp with the MLP on) - no other
+// evaluator is compiled in, so that the register limit of a two-wavefronts-per-SIMD kernel holds for all its callees
+template <typename T, int HS, int VAR = 0, bool JVP_ONLY = false>
 __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB, int stride, T* tile, int lane,
                                            const NnRole& role, const RodState<T>& y, const T (&hv)[HS], V3<T> tf,
                                            RodState<T>& ys, V3<T>& v, V3<T>& u) {
   T yr[19];
   state_to_rows(y, yr);
   if constexpr (HS != HS_NNH) {
-    if (M.mfma_ok) {  // wave-uniform: the 64 evaluations of the wave as GEMMs on the matrix cores
+    if (JVP_ONLY || M.mfma_ok) {  // wave-uniform: the 64 evaluations of the wave as GEMMs on the matrix cores
       T x[MM_IN];
 #pragma unroll
       for (int i = 0; i < 19; ++i) x[i] = yr[i];
       x[19] = v.x; x[20] = v.y; x[21] = v.z; x[22] = u.x; x[23] = u.y; x[24] = u.z;
       x[25] = tf.x; x[26] = tf.y; x[27] = tf.z;
       T d[25];
-      if (role.jvp && M.jvp_ok) mlp_jvp_eval<T>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d);  // wave-uniform choice
-      else mlp_mfma_eval<T>(M, x, tile, lane, d);
+      if constexpr (JVP_ONLY) {
+        mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d);
+      } else {
+        if (role.jvp && M.jvp_ok) mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d);  // wave-uniform choice
+        else mlp_mfma_eval<T>(M, x, tile, lane, d);
+      }
       T yr2[19];
       state_to_rows(ys, yr2);
 #pragma unroll
@@ -315,12 +321,12 @@ struct SweepCtx {
 };
 
 // one ODE evaluation incl. the optional network correction
-template <typename T, bool DIAG, bool NN, int HS>
+template <typename T, bool DIAG, bool NN, int HS, bool JVP_ONLY = false>
 __device__ __forceinline__ void eval_point(const RodConst<T>& P, const MlpDev<T>& M, const SweepCtx<T, HS>& C,
                                            const RodState<T>& y, const T (&hv)[HS], RodState<T>& k, V3<T>& v,
                                            V3<T>& u) {
   ode_eval<T, DIAG>(P, y, hist_from<T, HS>(hv), C.fconst, k, v, u);
-  if constexpr (NN) nn_correct<T, HS>(M, C.bufA, C.bufB, C.astride, C.tile, C.lane, C.role, y, hv, C.tf, k, v, u);
+  if constexpr (NN) nn_correct<T, HS, 0, JVP_ONLY>(M, C.bufA, C.bufB, C.astride, C.tile, C.lane, C.role, y, hv, C.tf, k, v, u);
 }
 
 template <typename T, bool DIAG, int SCHEME, bool HIST_LDS, bool NN, int HS>

@@ -211,7 +211,9 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
 // The base chain runs in fp64 for both sweep precisions (it is the faster matrix-core form for 4 samples), then the
 // JVP chain; pointers arrive as generic ones (the function is not inlined: one copy per activation in the library)
 // and are put back into their address spaces first - flat loads would serialise LDS and global traffic.
-template <typename T, int ACT>
+// VAR: a second copy of the function for the kernels built for two wavefronts per SIMD (the register limit of a kernel
+// reaches its callees only if all callers of a function agree on it)
+template <typename T, int ACT, int VAR = 0>
 __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_generic, int lane) {
   gf4p wq[3];
   gfp bq[3];
@@ -378,7 +380,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
 // col = 0 and a copy of their interval's state.  zrow: the dx row a lane without a column zeroes (the rows no column
 // owns: every sample tile has 16, an interval 6 or 16 columns; -1 = lane layout 7 + 3 x 17 of kr_ms_impl.hpp).
 // x in, NN(x) (base lanes) or NN(x_base) + J dx (the others) out.
-template <typename T>
+template <typename T, int VAR = 0>
 __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
                                              bool idle, int zrow, T (&out)[25]) {
   using V = typename MjVec<T>::type;
@@ -431,11 +433,11 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
   mm_wave_sync();
   const JvpNet net = jvp_net<T>(M);
   switch (M.acts[0]) {  // wave-uniform
-    case KR_ACT_TANH: mlp_jvp_tile<T, KR_ACT_TANH>(net, scratch, lane); break;
-    case KR_ACT_SOFTPLUS: mlp_jvp_tile<T, KR_ACT_SOFTPLUS>(net, scratch, lane); break;
-    case KR_ACT_RELU: mlp_jvp_tile<T, KR_ACT_RELU>(net, scratch, lane); break;
-    case KR_ACT_ELU: mlp_jvp_tile<T, KR_ACT_ELU>(net, scratch, lane); break;
-    default: mlp_jvp_tile<T, KR_ACT_NONE>(net, scratch, lane); break;
+    case KR_ACT_TANH: mlp_jvp_tile<T, KR_ACT_TANH, VAR>(net, scratch, lane); break;
+    case KR_ACT_SOFTPLUS: mlp_jvp_tile<T, KR_ACT_SOFTPLUS, VAR>(net, scratch, lane); break;
+    case KR_ACT_RELU: mlp_jvp_tile<T, KR_ACT_RELU, VAR>(net, scratch, lane); break;
+    case KR_ACT_ELU: mlp_jvp_tile<T, KR_ACT_ELU, VAR>(net, scratch, lane); break;
+    default: mlp_jvp_tile<T, KR_ACT_NONE, VAR>(net, scratch, lane); break;
   }
   {
     const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);

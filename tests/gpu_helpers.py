@@ -79,6 +79,8 @@ def expected_path(mode, N, mlp=None, scheme="euler"):
         return 1
     if N > PERSIST_MAX_N or (mlp is not None and scheme != "euler"):
         return 1
+    if mlp is not None and len(mlp.weights) == 3 and mlp.weights[1].shape[0] > 192:
+        return 1  # (the persistent kernels carry the base + JVP evaluator only: mlp_jvp.hpp, MJ_ACT_SLOTS)
     if mode == "overlap":  # Euler sweeps, MLP off, diagonal material matrices (every preset)
         return 3 if (mlp is None and scheme == "euler") else 2
     return 2
