@@ -89,6 +89,21 @@ __device__ __forceinline__ JvpNet jvp_net(const MlpDev<T>& M) {
   return n;
 }
 
+#ifdef MJ_STAMPS  // tools/ubench_jvp.hip: cycles per phase of one evaluation (wave 0 of block 0)
+__device__ unsigned long long mj_stamp_acc[16];
+#define MJ_STAMP(k)                                                                       \
+  do {                                                                                    \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* (vmcnt / lgkmcnt 0: charge a phase its own waits) */ \
+    const unsigned long long mj_now = __builtin_amdgcn_s_memtime();                       \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0) mj_stamp_acc[k] += mj_now - mj_t;            \
+    mj_t = mj_now;                                                                        \
+  } while (0)
+#define MJ_STAMP_BEGIN() unsigned long long mj_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define MJ_STAMP(k) do {} while (0)
+#define MJ_STAMP_BEGIN() do {} while (0)
+#endif
 #define MJ_LDS __attribute__((address_space(3)))
 #define MJ_GLB __attribute__((address_space(1)))
 typedef MJ_GLB const float* gfp;
@@ -153,6 +168,8 @@ __device__ __forceinline__ void chunk_operands(const double (&h)[4], double (&bv
 // activation of a chunk (4 values per lane, all of them real) and its act' to the table [interval j][unit]
 template <int ACT>
 __device__ __forceinline__ void chunk_activate(double (&h)[4], MJ_LDS float* actp, int lane) {
+  // (fp64 also for fp32 sweeps: converting to float for a v_exp_f32 activation was measured SLOWER, 16.8 k against
+  //  14.9 k cycles per evaluation in tools/ubench_jvp.hip)
   activate_block<double, ACT, 4>(h);
   const int unit0 = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
@@ -308,6 +325,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
   } else {
     // in -> H1 (<= 64: one chunk) -> H2 (<= 64 (MJ_ACT_SLOTS - 1)) -> 25: the whole base chain, then the whole JVP chain
     const int chunks2 = ots[1] / 4;
+    MJ_STAMP_BEGIN();
     f32x4 w1[2][4], w2[4][4], wo4[4][MM_OUT_T];
     base_load<4, 2>(w1, wq[0], 2, 0, 0, lane);
     base_load<4, 4>(w2, wq[1], 4, 0, 0, lane);
@@ -316,12 +334,15 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
     jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
     jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
     jvp_load<MM_OUT_T, 2>(ao, jq[2], jkss[2], 0, 0, lane);
+    MJ_STAMP(0);  // weight loads (waited for)
     {
       double h1[4];
 #pragma unroll
       for (int o = 0; o < 4; ++o) h1[o] = (double)bq[0][o * 64 + lane];
       base_run<4, 2>(h1, w1, [&](int ks) { return bin[ks]; });
+      MJ_STAMP(1);  // base layer 1
       chunk_activate<ACT>(h1, actp, lane);
+      MJ_STAMP(2);  // activation 1
 #pragma unroll 1
       for (int ch = 0; ch < chunks2; ++ch) {
         if (ch > 0) {
@@ -332,8 +353,11 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
 #pragma unroll
         for (int o = 0; o < 4; ++o) h2[o] = (double)bq[1][(4 * ch + o) * 64 + lane];
         base_run<4, 4>(h2, w2, [&](int ks) { return chunk_operand(h1, ks); });
+        MJ_STAMP(3);  // base layer 2
         chunk_activate<ACT>(h2, actp + (1 + ch) * 256, lane);
+        MJ_STAMP(4);  // activation 2
         out_layer(h2, wo4, std::false_type{});
+        MJ_STAMP(5);  // base output layer
       }
     }
     mm_wave_sync();
@@ -345,7 +369,9 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
       f32x4 dh[4][4];
       zero_dh(dh);
       jvp_accumulate<4, 1>(dh, a1, bdx);
+      MJ_STAMP(6);  // JVP layer 1
       jvp_scale_pack(dh, actp, lane, b1);
+      MJ_STAMP(7);  // scale + pack 1
     }
 #pragma unroll 1
     for (int ch = 0; ch < chunks2; ++ch) {
@@ -356,9 +382,12 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
       f32x4 dh[4][4];
       zero_dh(dh);
       jvp_accumulate<4, 2>(dh, a2, b1);
+      MJ_STAMP(8);  // JVP layer 2
       bf16x8 b2[4][2];
       jvp_scale_pack(dh, actp + (1 + ch) * 256, lane, b2);
+      MJ_STAMP(9);  // scale + pack 2
       jvp_accumulate<MM_OUT_T, 2>(ojvp, ao, b2);
+      MJ_STAMP(10);  // JVP output layer
     }
   }
   // results: base outputs over the input rows, J dx rows over the dx rows (every lane has read its operands; the

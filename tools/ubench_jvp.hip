@@ -34,6 +34,19 @@ __global__ __launch_bounds__(256) void k(MlpDev<T> M, T* out, unsigned long long
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+#ifdef MJ_STAMPS
+static void stamps(const char* name, int iters) {
+  unsigned long long h[16];
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(kr::mj_stamp_acc), sizeof(h));
+  const char* nm[11] = {"weight loads", "base L1", "act 1", "base L2", "act 2", "base out", "jvp L1", "pack 1", "jvp L2", "pack 2", "jvp out"};
+  double tot = 0;
+  printf("  %s, per evaluation:", name);
+  for (int k = 0; k < 11; ++k) { printf(" %s %.0f;", nm[k], (double)h[k] / iters); tot += (double)h[k] / iters; }
+  printf(" (sum %.0f)\n", tot);
+  unsigned long long z[16] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(kr::mj_stamp_acc), z, sizeof(z));
+}
+#endif
 template <typename T>
 void run(const char* name, std::vector<int> dims, int blocks) {
   const int L = (int)dims.size() - 1;
@@ -61,6 +74,9 @@ void run(const char* name, std::vector<int> dims, int blocks) {
   std::vector<unsigned long long> h(blocks); (void)hipMemcpy(h.data(), cyc, 8 * blocks, hipMemcpyDeviceToHost);
   double s = 0; for (auto v : h) s += (double)v;
   printf("%s blocks=%d: %.0f cycles per evaluation\n", name, blocks, s / blocks / iters);
+#ifdef MJ_STAMPS
+  stamps(name, iters);
+#endif
 }
 int main() {
   for (int blocks : {1, 256}) {
