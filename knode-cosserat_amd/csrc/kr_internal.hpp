@@ -209,6 +209,9 @@ template <typename T>
 int nn_sim_waves_per_rod(kr_handle* h, int scheme, int64_t B);
 template <typename T>
 int launch_msw_nn_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s);
+// ... and with the MLP off, for rods too long for the LDS form (N = 400); returns 1 when it does not apply either
+template <typename T>
+int launch_msw_gh_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s);
 int ensure_hist_ws(kr_handle* h, size_t bytes);
 // kr_sim_f32.hip / kr_sim_f64.hip: the same for the one-wavefront persistent kernel that runs behind it
 template <typename T>

@@ -777,7 +777,9 @@ __device__ __forceinline__ void msw_apply(const MswLds<T, W>& L, const MswRole& 
 
 // ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
 // hist: the history records [N][HS_LEAN] (LDS, or global memory in the persistent kernel with the MLP on)
-template <typename T, bool DIAG, int W, bool NN = false, int EV = 0>
+// PF2: the record of grid point j + 2 is requested while point j is evaluated (history in global memory, MLP off: one
+// evaluation, not the few instructions between two of them, has to cover an L2 round trip)
+template <typename T, bool DIAG, int W, bool NN = false, int EV = 0, bool PF2 = false>
 __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
                                           V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps,
                                           const T* hist, const MswNn<T>& nn) {
@@ -817,12 +819,15 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
     const bool st = (storing || flush) && col == 0 && !idle;
 
     // ---- sweep over this lane's sub-interval (explicit Euler, cosserat_ode.py:198-201) ------------------
-    T hv[HS_LEAN];
+    T hv[HS_LEAN], hn[PF2 ? HS_LEAN : 1];
     load_hist_vec<T, HS_LEAN>(hist + (size_t)R.s_i * HS_LEAN, hv);
+    if constexpr (PF2) load_hist_vec<T, HS_LEAN>(hist + (size_t)(R.s_i + 1) * HS_LEAN, hn);
     auto point = [&](auto store_tag, int j, bool live) __attribute__((always_inline)) {
       constexpr bool STORE = decltype(store_tag)::value;
       RodState<T> k1;
       V3<T> v, u;
+      T h2[PF2 ? HS_LEAN : 1];
+      if constexpr (PF2) load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 2 < N ? j + 2 : N - 1) * HS_LEAN, h2);
       ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
 #ifndef KR_MSWN_NO_EVAL
       if constexpr (NN)  // every wavefront evaluates the network for its own lanes (cosserat_ode.py:169-184)
@@ -844,7 +849,12 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
           }
         }
       }
-      load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 1) * HS_LEAN, hv);
+      if constexpr (PF2) {
+#pragma unroll
+        for (int c = 0; c < HS_LEAN; ++c) { hv[c] = hn[c]; hn[c] = h2[c]; }
+      } else {
+        load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 1) * HS_LEAN, hv);
+      }
       y = state_axpy(y, Pc.ds, k1);
     };
     if constexpr (NN) {
@@ -1273,13 +1283,20 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
 // grid point then costs ~20 k cycles of network evaluation, against which an L2-resident 96-byte read is nothing, and
 // without them four rods fit the LDS of a CU in fp64 too: 1024 rods run at two wavefronts per SIMD, each sweeping a
 // chain half as long, and the waits of one wavefront's evaluator chain are filled by the other's.
+// HM, where the time history lives: 0 everything in LDS (short rods, MLP off); 2 everything in global memory (MLP on);
+// 1 the history records in LDS, the two newest states in A.states (MLP off, rods whose leading slots do not fit next to
+// the records: N = 400, cfg5 - a rod then takes what the one-launch-per-step kernel takes, 76 KB in fp64 at W = 2).
 template <typename T, int W>
-__host__ __device__ inline size_t msw_sim_lds_elems(int N, bool nn = false) {
-  return nn ? msw_lds_elems<T, W>(N, true, false) : msw_lds_elems<T, W>(N) + (size_t)2 * N * 12;
+__host__ __device__ inline size_t msw_sim_lds_elems(int N, bool nn = false, int hm = 0) {
+  if (nn) hm = 2;
+  return msw_lds_elems<T, W>(N, nn, hm != 2) + (hm == 0 ? (size_t)2 * N * 12 : 0);
 }
 
-template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1>
+template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1, int HM = NN ? 2 : 0>
 __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A, const MlpDev<T> M) {
+  static_assert(HM == 2 || !NN, "the MLP-on instantiations keep their history in global memory");
+  constexpr bool GH = HM == 2;   // history records in global memory
+  constexpr bool GL = HM != 0;   // the two newest states read from A.states instead of an LDS copy of their leading slots
   constexpr int P = MswGeo<W>::P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = Pc.N;
@@ -1288,16 +1305,16 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   const int64_t rod = blockIdx.x;
   const size_t rod_elems = (size_t)N * KR_SLOTS;
   T* smem = reinterpret_cast<T*>(smem_raw);
-  const MswLds<T, W> L = msw_carve<T, W>(smem, N, NN, !NN);
-  T* lead0 = NN ? nullptr : smem + msw_lds_elems<T, W>(N);  // [2][N][12]: newest state / the one before (roles alternate)
-  const T* hist = NN ? A.hist_ws + (size_t)rod * N * HS_LEAN : L.hist;
+  const MswLds<T, W> L = msw_carve<T, W>(smem, N, NN, !GH);
+  T* lead0 = GL ? nullptr : smem + msw_lds_elems<T, W>(N);  // [2][N][12]: newest state / the one before (roles alternate)
+  const T* hist = GH ? A.hist_ws + (size_t)rod * N * HS_LEAN : L.hist;
   const int lsz = N * 12;
   const MswRole R = msw_role<W>(wave, lane, N);
   MsStamps stamps;
   if (wave == 0) ms_cold_fill<T>(Pc, L.cold, lane);
   const T* s0 = A.states + rod * rod_elems;
   const T* sp = A.prev_init ? A.prev_init + rod * rod_elems : s0;
-  if constexpr (!NN) {
+  if constexpr (!GL) {
     for (int j = threadIdx.x; j < N; j += WAVE * W) {
       T cv[12], pv[12];
       load_hist_vec<T, 12>(s0 + (size_t)j * KR_SLOTS, cv);
@@ -1321,12 +1338,12 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   __syncthreads();
   for (int64_t t = 0; t < A.T_steps; ++t) {
     T* prv = nullptr;
-    if constexpr (NN) {
+    if constexpr (GL) {
       // BDF2 history (knode.py:74-75) from the two newest states in A.states (this workgroup wrote them: visible after
-      // the barrier that ended the step), into the rod's rows of the workspace
+      // the barrier that ended the step), into the rod's rows of the workspace or its LDS records
       const T* rc = A.states + (A.ring ? t % 3 : t) * A.slot_elems + rod * rod_elems;
       const T* rp = t > 0 ? A.states + (A.ring ? (t - 1) % 3 : t - 1) * A.slot_elems + rod * rod_elems : sp;
-      T* hw = A.hist_ws + (size_t)rod * N * HS_LEAN;
+      T* hw = GH ? A.hist_ws + (size_t)rod * N * HS_LEAN : L.hist;
       for (int j = threadIdx.x; j < N; j += WAVE * W) {
         T cv[12], pv[12], hv[12];
         load_hist_vec<T, 12>(rc + (size_t)j * KR_SLOTS, cv);
@@ -1381,7 +1398,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       wave_sync();
       if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
       __syncthreads();
-      status = msw_newton<T, DIAG, W, NN, OCC - 1>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
+      status = msw_newton<T, DIAG, W, NN, OCC - 1, GH && !NN>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
@@ -1411,10 +1428,10 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   }
 }
 
-template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1>
+template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1, int HM = NN ? 2 : 0>
 static int launch_msw_sim_inst(const RodConst<T>& P, const MlpDev<T>& M, const SimArgs<T>& a, hipStream_t s) {
-  auto kern = msw_sim_kernel<T, DIAG, W, NN, OCC>;
-  const size_t smem = sizeof(T) * msw_sim_lds_elems<T, W>(P.N, NN);
+  auto kern = msw_sim_kernel<T, DIAG, W, NN, OCC, HM>;
+  const size_t smem = sizeof(T) * msw_sim_lds_elems<T, W>(P.N, NN, HM);
   static thread_local size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1429,9 +1446,9 @@ template <typename T>
 static int launch_msw_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s) {
   const RodConst<T>& P = consts<T>(h);
   const size_t bytes = sizeof(T) * (W == 2 ? msw_sim_lds_elems<T, 2>(P.N) : msw_sim_lds_elems<T, 4>(P.N));
-  if (bytes > (size_t)h->lds_limit) return 1;
-  const int64_t per_cu = (int64_t)((size_t)h->lds_limit / bytes);
-  if (a.B > 256 * per_cu) return 1;  // (a second round of workgroups would wait for the first to finish all steps)
+  // (every rod resident at once: a second round of workgroups would wait for the first to finish all steps)
+  if (bytes > (size_t)h->lds_limit || a.B > 256 * (int64_t)((size_t)h->lds_limit / bytes))
+    return launch_msw_gh_sim<T>(h, W, a, s);  // long rods: the form that reads the two newest states from A.states
   h->last_waves_per_rod = W;
   const MlpDev<T>& M = mlpdev<T>(h);
   if (W == 2) return P.diag ? launch_msw_sim_inst<T, true, 2>(P, M, a, s) : launch_msw_sim_inst<T, false, 2>(P, M, a, s);

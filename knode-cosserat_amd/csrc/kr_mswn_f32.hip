@@ -4,4 +4,5 @@
 namespace kr {
 template int nn_sim_waves_per_rod<float>(kr_handle*, int, int64_t);
 template int launch_msw_nn_sim<float>(kr_handle*, int, const SimArgs<float>&, hipStream_t);
+template int launch_msw_gh_sim<float>(kr_handle*, int, const SimArgs<float>&, hipStream_t);
 }

@@ -4,4 +4,5 @@
 namespace kr {
 template int nn_sim_waves_per_rod<double>(kr_handle*, int, int64_t);
 template int launch_msw_nn_sim<double>(kr_handle*, int, const SimArgs<double>&, hipStream_t);
+template int launch_msw_gh_sim<double>(kr_handle*, int, const SimArgs<double>&, hipStream_t);
 }

@@ -55,4 +55,21 @@ int launch_msw_nn_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s) {
   return W == 2 ? launch_msw_sim_inst<T, true, 2, true>(P, M, a2, s) : launch_msw_sim_inst<T, true, 4, true>(P, M, a2, s);
 }
 
+
+// MLP off, long rods (HM = 1: history records in LDS, the two newest states read from A.states): what launch_msw_sim
+// (kr_msw_impl.hpp) falls to when the leading slots of two states do not fit the LDS next to everything else (N = 400:
+// 77 KB on top of 38 KB of records and 19 KB per wavefront)
+template <typename T>
+int launch_msw_gh_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s) {
+  const RodConst<T>& P = consts<T>(h);
+  const MlpDev<T>& M = mlpdev<T>(h);
+  if (W != 2 && W != 4) return 1;
+  const size_t bytes = sizeof(T) * (W == 2 ? msw_sim_lds_elems<T, 2>(P.N, false, 1) : msw_sim_lds_elems<T, 4>(P.N, false, 1));
+  if (bytes > (size_t)h->lds_limit || a.B > 256 * (int64_t)((size_t)h->lds_limit / bytes)) return 1;
+  h->last_waves_per_rod = W;
+  if (W == 2)
+    return P.diag ? launch_msw_sim_inst<T, true, 2, false, 1, 1>(P, M, a, s) : launch_msw_sim_inst<T, false, 2, false, 1, 1>(P, M, a, s);
+  return P.diag ? launch_msw_sim_inst<T, true, 4, false, 1, 1>(P, M, a, s) : launch_msw_sim_inst<T, false, 4, false, 1, 1>(P, M, a, s);
+}
+
 }  // namespace kr

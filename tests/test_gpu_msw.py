@@ -196,6 +196,65 @@ def _assert_persistent(h, waves):
     assert h.get_option("last_sim_path") == 2 and h.get_option("last_waves_per_rod") == waves
 
 
+@pytest.mark.parametrize("P", ["0_5", "1_0", "3_0"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_n400_persistent_vs_reference(torch_cuda, waves_persistent, P, dtype):
+    """N = 400 in ONE launch for all steps: the records of such a rod do not fit the LDS, so the persistent kernel keeps its
+    history records in global memory (msw_sim_kernel<..., GH>, kr_mswn_impl.hpp: launch_msw_gh_sim).  Same fixtures and
+    bars as the one-launch-per-step form above."""
+    from knode import simulate_batch
+    ctl, tip, last, ier = _n400_case(P)
+    assert np.all(ier == 1)
+    r = make_robot(None, 400)
+    T = len(tip) - 1
+    out = simulate_batch(r, ctl[None, :T], dtype=dtype)
+    _assert_persistent(r._native(), waves_persistent)
+    assert np.all(out["status"] == 0)
+    got = np.concatenate([out["traj"][0, :1, :3, -1], out["tip"][0]])
+    assert rel_l2(got, tip) < (1e-8 if dtype == "f64" else 1e-5)
+    assert rel_l2(out["traj"][0, T], last) < (1e-7 if dtype == "f64" else 2e-5)
+
+
+def test_n400_persistent_batch(torch_cuda, monkeypatch):
+    """The cfg5 batch (B = 512, N = 400, two wavefronts per rod) through the persistent long-rod form: ring call, every step
+    converged, tips equal to those of the one-launch-per-step kernel to what the tolerance leaves, chunked calls with the
+    predictor images carried through HBM equal to one call."""
+    import torch
+    import cosserat_oracle as orc
+    B, N, T = 512, 400, 12
+    ctl_np = orc.batch_sine_controls(B, T, 0.05, 77)
+    tips = {}
+    for persistent in (1, 0):
+        set_mode_env(monkeypatch, "persistent" if persistent else "multi", waves_per_rod=0)
+        h = make_robot(None, N)._native()
+        ctl = torch.as_tensor(ctl_np, device=DEV).contiguous()
+        st = h.new_state(B, torch.float64, n_slots=3)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=torch.float64, device=DEV)
+        tip = torch.empty((B, T, 3), dtype=torch.float64, device=DEV)
+        status = torch.full((B, T), -1, dtype=torch.int32, device=DEV)
+        h.simulate(ctl, st, G, ring=True, tip=tip, status=status)
+        torch.cuda.synchronize()
+        assert h.get_option("last_sim_path") == (2 if persistent else 1) and h.get_option("last_waves_per_rod") == 2
+        assert int((status != 0).sum()) == 0
+        tips[persistent] = tip.cpu().numpy()
+        if persistent:  # the same in two calls (state history: three slots are not enough to chunk a ring, use full slots)
+            h.set_option("keep_predictor", 1)
+            st2 = h.new_state(B, torch.float64, n_slots=T + 1)
+            h.init_straight(st2[0])
+            G2 = torch.zeros((B, 6), dtype=torch.float64, device=DEV)
+            tip2 = torch.empty((B, T, 3), dtype=torch.float64, device=DEV)
+            for t0, n in ((0, 5), (5, 7)):
+                tp = torch.empty((B, n, 3), dtype=torch.float64, device=DEV)
+                h.simulate(ctl[:, t0:t0 + n].contiguous(), st2[t0:], G2, tip=tp, prev_init=st2[t0 - 1] if t0 else None)
+                tip2[:, t0:t0 + n] = tp
+            torch.cuda.synchronize()
+            assert h.get_option("last_sim_path") == 2
+            assert np.max(np.abs(tip2.cpu().numpy() - tips[1])) < 1e-8
+            h.set_option("keep_predictor", 0)
+    assert np.max(np.abs(tips[1] - tips[0])) < 1e-8
+
+
 @pytest.mark.parametrize("N,mod", [(27, None), (100, None), (100, "dampstiff"), (131, None), (200, "dampstiff")])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_persistent_vs_oracle(torch_cuda, waves_persistent, N, mod, dtype):
@@ -335,8 +394,8 @@ def test_hard_step_status_does_not_depend_on_the_kernel(torch_cuda, monkeypatch,
 
 
 def test_auto_choice(torch_cuda, monkeypatch):
-    """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512, one beyond (one
-    launch per step: no persistent form fits); N = 100 runs the persistent several-wavefront kernel with four up to
+    """Without the override: N = 400 takes four wavefronts per rod up to B = 256, two up to B = 512 (one launch for all
+    steps, history records in global memory), one beyond (one launch per step); N = 100 runs the persistent several-wavefront kernel with four up to
     B = 256, two up to B = 512 and the persistent one-wavefront kernel beyond; N = 20 always the latter."""
     torch = torch_cuda
     set_mode_env(monkeypatch, "persistent", waves_per_rod=0)
@@ -354,7 +413,10 @@ def test_auto_choice(torch_cuda, monkeypatch):
     h = make_robot(None, 400)._native()
     for B, want in ((1, 4), (256, 4), (257, 2), (512, 2), (513, 1)):
         run(h, B)
-        assert_path(h, 1, want)
+        if want > 1:
+            assert h.get_option("last_sim_path") == 2 and h.get_option("last_waves_per_rod") == want, (B, want)
+        else:
+            assert_path(h, 1, want)
     h = make_robot(None, 100)._native()
     for B, want in ((4, 4), (256, 4), (257, 2), (512, 2), (513, 1)):
         run(h, B)
