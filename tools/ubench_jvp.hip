@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
 #include "../knode-cosserat_amd/csrc/mlp_jvp.hpp"
 namespace kr { void set_error(const std::string&) {} int hip_fail(hipError_t, const char*) { return -2; } int ensure_ws(kr_handle*, size_t) { return 0; } }
 using namespace kr;
@@ -59,9 +60,23 @@ void run(const char* name, std::vector<int> dims, int blocks) {
     const int kg = kk == 0 ? 2 : prev;
     const int jks = kk == 0 ? 1 : prev / 2;
     float *w, *b; void* j;
-    (void)hipMalloc(&w, 16 * tiles * kg * 64); (void)hipMemset(w, 0, 16 * tiles * kg * 64);
-    (void)hipMalloc(&b, 4 * tiles * 64); (void)hipMemset(b, 0, 4 * tiles * 64);
-    (void)hipMalloc(&j, 16 * tiles * jks * 64); (void)hipMemset(j, 0, 16 * tiles * jks * 64);
+    // pseudo-random fragments (not a real network: the point is a data-dependent checksum that a re-ordering of the
+    // evaluator must reproduce bit for bit)
+    auto fill = [&](void* dst, size_t bytes, bool bf16) {
+      std::vector<unsigned> hbuf(bytes / 4);
+      unsigned st = 12345u + (unsigned)kk * 7919u + (unsigned)bytes;
+      for (auto& v : hbuf) {
+        st = st * 1664525u + 1013904223u;
+        const float f = ((int)(st >> 8) % 2001 - 1000) * 1e-4f;  // |f| <= 0.1
+        unsigned bits; memcpy(&bits, &f, 4);
+        if (bf16) { st = st * 1664525u + 1013904223u; const float g = ((int)(st >> 8) % 2001 - 1000) * 1e-4f; unsigned b2; memcpy(&b2, &g, 4); v = (bits >> 16) | (b2 & 0xFFFF0000u); }
+        else v = bits;
+      }
+      (void)hipMemcpy(dst, hbuf.data(), bytes, hipMemcpyHostToDevice);
+    };
+    (void)hipMalloc(&w, 16 * tiles * kg * 64); fill(w, 16 * tiles * kg * 64, false);
+    (void)hipMalloc(&b, 4 * tiles * 64); fill(b, 4 * tiles * 64, false);
+    (void)hipMalloc(&j, 16 * tiles * jks * 64); fill(j, 16 * tiles * jks * 64, true);
     M.wq[kk] = w; M.bq[kk] = b; M.kgroups[kk] = kg; M.otiles[kk] = tiles; M.acts[kk] = last ? KR_ACT_NONE : KR_ACT_ELU;
     M.jfrag[kk] = j; M.jksteps[kk] = jks;
     M.dims[kk] = dims[kk]; prev = tiles;
@@ -73,7 +88,9 @@ void run(const char* name, std::vector<int> dims, int blocks) {
   (void)hipDeviceSynchronize();
   std::vector<unsigned long long> h(blocks); (void)hipMemcpy(h.data(), cyc, 8 * blocks, hipMemcpyDeviceToHost);
   double s = 0; for (auto v : h) s += (double)v;
-  printf("%s blocks=%d: %.0f cycles per evaluation\n", name, blocks, s / blocks / iters);
+  std::vector<T> ho(256); (void)hipMemcpy(ho.data(), out, sizeof(T) * 256, hipMemcpyDeviceToHost);
+  double cs = 0; for (int i = 0; i < 256; ++i) cs += (double)ho[i] * (1 + i % 7);
+  printf("%s blocks=%d: %.0f cycles per evaluation, checksum %.17g\n", name, blocks, s / blocks / iters, cs);
 #ifdef MJ_STAMPS
   stamps(name, iters);
 #endif
