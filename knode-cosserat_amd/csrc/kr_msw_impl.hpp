@@ -1467,7 +1467,7 @@ static size_t msw_lds_bytes(int N) { return sizeof(T) * msw_lds_elems<T, W>(N); 
 //   100  256        35.9            30.3            26.9             23.6
 //   100  512        36.5             -              29.5              -
 //   128  256     (47.7 per step)    32.6            31.1             25.6
-//   400  256    (115 per step)      59.5             -                -      (no persistent form: LDS)
+//   400  256    (115 per step)      59.5             -              52.6     (persistent: the long-rod form, HM = 1)
 template <typename T>
 int step_waves_per_rod(kr_handle* h, int scheme, int use_nn, int64_t B, int mode) {
   const RodConst<T>& P = consts<T>(h);
