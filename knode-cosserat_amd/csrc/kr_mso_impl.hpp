@@ -149,6 +149,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
   bool belowB = false;
   int itB = 0, orderB = 0;
   bool pred_skip = false;  // the predictor has already consumed step tA (a verifying sweep of it was rejected)
+  bool reverify = false;   // the coming merged sweep verifies step tA - 1 for the second time (after a chord update)
   int64_t resume_at = T_steps;
   T Xreg[MS_P - 1][2];
 #pragma unroll
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
         if (lane == 0 && A.status) A.status[rod * T_steps + tB] = KR_ST_CONVERGED;
         if (lane < 6) Gguess = XsB[0 * MS_YP + 7 + lane];
         pred_skip = false;
+        reverify = false;
         merged = false;
         if (!runA) break;  // that was the last step
       } else {
@@ -486,6 +488,26 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
         const bool ok = dnv <= 3.0e38f;
         if (ok) apply(XsB);
         wave_sync_lds();
+        if (ok && !reverify && itB + 2 <= maxit) {
+          // First rejection of this step, and the chord update is a proper Newton-type correction (its factors are one
+          // iteration old): verify AGAIN in a merged sweep instead of falling back to two plain ones.  The history of
+          // step tB comes back from HBM, the forward-difference lanes repeat their sweep of step tA from the same
+          // start (what they computed above used a history that was off by this correction) - everything else is as
+          // it was when the rejected sweep began, so a rejection costs one merged sweep instead of two plain sweeps
+          // plus the restart of step tA.  In a short launch the slowest rod sets the time, and the slowest rod is the
+          // one with rejections.
+          reverify = true;
+          itB += 1;
+          dnB = (T)dnv;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the records streamed out above are re-read below
+          rebuild(tB);
+#ifdef KR_MS_STAMPS
+          st.rebuilds += 1;
+          KR_STAMP_ADD(st.t_alg, tq);
+#endif
+          continue;
+        }
+        reverify = false;
         for (int e = lane; e < MS_NE; e += WAVE) Xs[e] = XsB[e];
         tA = tB;
         fcN = fcA;
