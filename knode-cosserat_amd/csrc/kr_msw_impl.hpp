@@ -777,9 +777,7 @@ __device__ __forceinline__ void msw_apply(const MswLds<T, W>& L, const MswRole& 
 
 // ---- Newton iteration of one rod on W wavefronts ----------------------------------------------------------------
 // hist: the history records [N][HS_LEAN] (LDS, or global memory in the persistent kernel with the MLP on)
-// PF2: the record of grid point j + 2 is requested while point j is evaluated (history in global memory, MLP off: one
-// evaluation, not the few instructions between two of them, has to cover an L2 round trip)
-template <typename T, bool DIAG, int W, bool NN = false, int EV = 0, bool PF2 = false>
+template <typename T, bool DIAG, int W, bool NN = false, int EV = 0>
 __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T, W>& L, const MswRole& R, int lane,
                                           V3<T> fconst, MsSolveArgs<T>& S, int& it, MsStamps& stamps,
                                           const T* hist, const MswNn<T>& nn) {
@@ -819,15 +817,12 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
     const bool st = (storing || flush) && col == 0 && !idle;
 
     // ---- sweep over this lane's sub-interval (explicit Euler, cosserat_ode.py:198-201) ------------------
-    T hv[HS_LEAN], hn[PF2 ? HS_LEAN : 1];
+    T hv[HS_LEAN];
     load_hist_vec<T, HS_LEAN>(hist + (size_t)R.s_i * HS_LEAN, hv);
-    if constexpr (PF2) load_hist_vec<T, HS_LEAN>(hist + (size_t)(R.s_i + 1) * HS_LEAN, hn);
     auto point = [&](auto store_tag, int j, bool live) __attribute__((always_inline)) {
       constexpr bool STORE = decltype(store_tag)::value;
       RodState<T> k1;
       V3<T> v, u;
-      T h2[PF2 ? HS_LEAN : 1];
-      if constexpr (PF2) load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 2 < N ? j + 2 : N - 1) * HS_LEAN, h2);
       ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
 #ifndef KR_MSWN_NO_EVAL
       if constexpr (NN)  // every wavefront evaluates the network for its own lanes (cosserat_ode.py:169-184)
@@ -849,12 +844,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
           }
         }
       }
-      if constexpr (PF2) {
-#pragma unroll
-        for (int c = 0; c < HS_LEAN; ++c) { hv[c] = hn[c]; hn[c] = h2[c]; }
-      } else {
-        load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 1) * HS_LEAN, hv);
-      }
+      load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 1) * HS_LEAN, hv);
       y = state_axpy(y, Pc.ds, k1);
     };
     if constexpr (NN) {
@@ -1398,7 +1388,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       wave_sync();
       if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
       __syncthreads();
-      status = msw_newton<T, DIAG, W, NN, OCC - 1, GH && !NN>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
+      status = msw_newton<T, DIAG, W, NN, OCC - 1>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
