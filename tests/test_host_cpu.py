@@ -391,3 +391,31 @@ def test_estimate_state_oracle_matches_reference(N):
         err = np.linalg.norm(est[:, rows] - want[:, rows]) / np.linalg.norm(want[:, rows])
         assert err < 1e-9, (name, err)
     assert np.allclose(np.asarray(r.vstar, dtype=np.float64), g[f"N{N}_vstar_after"], rtol=0, atol=1e-12)
+
+
+def test_wwm_spill_scanner(tmp_path):
+    """tools/wwm_spill_scan.py: an ordinary VGPR spill inside a whole-wave-mode bracket is
+    flagged, the save of an SGPR-spill register and a spill outside a bracket are not."""
+    import subprocess
+    import sys
+    asm = tmp_path / "k.s"
+    asm.write_text("""
+_ZN2kr6kernelEv:
+	v_writelane_b32 v255, s4, 3
+	scratch_store_dwordx4 off, v[2:5], off offset:608 ; 16-byte Folded Spill
+	s_or_saveexec_b64 s[100:101], -1
+	scratch_store_dword off, v255, off offset:16 ; 4-byte Folded Spill
+	s_mov_b64 exec, s[100:101]
+	s_or_saveexec_b64 s[100:101], -1
+	v_mov_b32_e32 v255, v250
+	scratch_store_dwordx4 off, v[2:5], off offset:608 ; 16-byte Folded Spill
+	s_mov_b64 exec, s[100:101]
+	s_endpgm
+""")
+    tool = os.path.join(ROOT, "tools", "wwm_spill_scan.py")
+    r = subprocess.run([sys.executable, tool, str(asm)], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 spill(s)" in r.stdout and "offset:608" in r.stdout, r.stdout
+    clean = tmp_path / "c.s"
+    clean.write_text(asm.read_text().replace("	v_mov_b32_e32 v255, v250\n	scratch_store_dwordx4 off, v[2:5], off offset:608 ; 16-byte Folded Spill\n", "	v_mov_b32_e32 v255, v250\n"))
+    r = subprocess.run([sys.executable, tool, str(clean)], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 spill(s)" in r.stdout, r.stdout
