@@ -1027,12 +1027,17 @@ __device__ __forceinline__ bool ms_base_bc(const T* cold, int r, T& g) {
 static_assert(MS_YP == 19, "Xs is indexed as one flat vector by the predictor");
 constexpr int MS_NE = MS_P * 19;
 constexpr int MS_EPL = (MS_NE + WAVE - 1) / WAVE;
-template <typename T>
+// NC: taps of the fitted recurrence.  3 with the MLP off (a constant plus one oscillation: what a rod driven by smooth
+// tensions does, predicted to ~5e-6); 5 with the MLP on - the network makes the response nonlinear, its harmonics need two
+// more taps (first guess 5e-3 -> 8e-4 on the fast rods of cfg3, 8e-4 -> 4e-5 on slow ones; measured with the oracle).
+template <typename T, int NC = 3>
 struct MsPred {
+  static_assert(NC == 3 || NC == 5, "three or five taps");
+  static constexpr int nc = NC;
   T Hx[MS_EPL][MS_HLEV];  // Hx[q][k]: element lane + 64 q, k steps back
-  // adaptive linear predictor: x(t+1) ~ a0 x(t) + a1 (x(t) - x(t-1)) + a2 (x(t) - 2 x(t-1) + x(t-2)) with the
-  // three coefficients fitted per rod (a = (1, 1, 1) is quadratic extrapolation)
-  double lpa[3];
+  // adaptive linear predictor: x(t+1) ~ a0 x(t) + a1 (x(t) - x(t-1)) + a2 (x(t) - 2 x(t-1) + x(t-2)) [+ a3, a4 times the
+  // third and fourth backward difference] with the coefficients fitted per rod (a = (1, 1, 1) is quadratic extrapolation)
+  double lpa[NC];
   bool lp_have;    // lpa was fitted on the previous step (so it can be tested on this one)
   bool lp_good;    // ... and predicted this step to better than 1e-3
   int lp_age;      // steps since lpa was fitted (a good fit is kept for a few steps)
@@ -1040,11 +1045,85 @@ struct MsPred {
   int next_order;  // extrapolation order of the coming step (MS_ORDER_LP: the linear predictor)
   T kappa;         // contraction constant handed to ms_newton (MsSolveArgs::kappa)
 };
+// backward differences of the time levels: the basis of the fitted recurrence
+template <typename T, int NC>
+__device__ __forceinline__ void lp_basis(const T (&H)[MS_HLEV], double (&b)[NC]) {
+  const double h0 = (double)H[0], h1 = (double)H[1], h2 = (double)H[2];
+  b[0] = h0; b[1] = h0 - h1; b[2] = h0 - 2.0 * h1 + h2;
+  if constexpr (NC == 5) {
+    const double h3 = (double)H[3], h4 = (double)H[4];
+    b[3] = h0 - 3.0 * h1 + 3.0 * h2 - h3;
+    b[4] = h0 - 4.0 * h1 + 6.0 * h2 - 4.0 * h3 + h4;
+  }
+}
+template <int NC>
+__device__ __forceinline__ double lp_eval(const double (&a)[NC], const double (&b)[NC]) {
+  double s = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];  // (the order of the three-tap version)
+  if constexpr (NC == 5) s += a[3] * b[3] + a[4] * b[4];
+  return s;
+}
+// normal equations of the weighted fit: upper triangle row by row, then the right-hand side
+template <int NC>
+constexpr int lp_nsum() { return NC * (NC + 1) / 2 + NC; }
+template <int NC>
+__device__ __forceinline__ void lp_accumulate(double (&Sn)[NC * (NC + 1) / 2 + NC], const double (&b)[NC], double x, double w) {
+  double wb[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) wb[i] = b[i] * w;
+  const double xw = x * w;
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = i; j < NC; ++j) Sn[k++] += wb[i] * wb[j];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) Sn[k++] += wb[i] * xw;
+}
+// (N + lam diag N) a = r + lam diag(N) 1: ridge towards polynomial extrapolation, relative per column; symmetric positive
+// definite: elimination without pivoting.  false: no usable fit.
+template <int NC>
+__device__ __forceinline__ bool lp_solve(const double (&Sn)[NC * (NC + 1) / 2 + NC], double (&a)[NC]) {
+  const double lam = 1e-12;
+  double m[NC][NC + 1];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int j = i; j < NC; ++j) { m[i][j] = Sn[k]; m[j][i] = Sn[k]; ++k; }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { m[i][NC] = Sn[k++] + lam * m[i][i]; m[i][i] *= (1 + lam); }
+  }
+  double inv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    inv[c] = fast_rcp(m[c][c]);
+#pragma unroll
+    for (int i = c + 1; i < NC; ++i) {
+      const double f = m[i][c] * inv[c];
+#pragma unroll
+      for (int j = c + 1; j <= NC; ++j) m[i][j] -= f * m[c][j];
+    }
+  }
+  bool ok = true;
+  double bound = 4.0;
+#pragma unroll
+  for (int i = NC - 1; i >= 0; --i) {
+    double r = m[i][NC];
+#pragma unroll
+    for (int j = i + 1; j < NC; ++j) r -= m[i][j] * a[j];
+    a[i] = r * inv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) { ok = ok && isfinite(a[i]) && fabs(a[i]) < bound; bound *= 4.0; }
+  return ok;
+}
+
 constexpr int MS_PRED_ROWS = MS_EPL * MS_HLEV + 8;  // doubles per lane of the HBM image
 static_assert((size_t)MS_PRED_ROWS * WAVE == KR_PRED_IMG_DOUBLES, "kr_internal.hpp sizes the image buffer");
 
-template <typename T>
-__device__ __forceinline__ void ms_pred_init(MsPred<T>& Q, int lane, const MsRole& R, const T* s0, const T* sp,
+template <typename T, int NC>
+__device__ __forceinline__ void ms_pred_init(MsPred<T, NC>& Q, int lane, const MsRole& R, const T* s0, const T* sp,
                                              bool has_prev, int predictor) {
 #pragma unroll
   for (int q = 0; q < MS_EPL; ++q) {
@@ -1055,7 +1134,8 @@ __device__ __forceinline__ void ms_pred_init(MsPred<T>& Q, int lane, const MsRol
 #pragma unroll
     for (int k = 1; k < MS_HLEV; ++k) Q.Hx[q][k] = sp[off];
   }
-  Q.lpa[0] = Q.lpa[1] = Q.lpa[2] = 1.0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) Q.lpa[k] = 1.0;
   Q.lp_have = Q.lp_good = false;
   Q.lp_age = 0;
   Q.avail = has_prev ? 1 : 0;
@@ -1063,8 +1143,8 @@ __device__ __forceinline__ void ms_pred_init(MsPred<T>& Q, int lane, const MsRol
   if (Q.next_order >= MS_HLEV) Q.next_order = MS_HLEV - 1;
   Q.kappa = T(0);
 }
-template <typename T>
-__device__ __forceinline__ void ms_pred_save(const MsPred<T>& Q, double* img, int lane) {
+template <typename T, int NC>
+__device__ __forceinline__ void ms_pred_save(const MsPred<T, NC>& Q, double* img, int lane) {
 #pragma unroll
   for (int q = 0; q < MS_EPL; ++q)
 #pragma unroll
@@ -1073,10 +1153,14 @@ __device__ __forceinline__ void ms_pred_save(const MsPred<T>& Q, double* img, in
   u[0 * WAVE + lane] = Q.lpa[0]; u[1 * WAVE + lane] = Q.lpa[1]; u[2 * WAVE + lane] = Q.lpa[2];
   u[3 * WAVE + lane] = (double)Q.kappa;
   u[4 * WAVE + lane] = (double)Q.avail; u[5 * WAVE + lane] = (double)Q.next_order;
-  u[6 * WAVE + lane] = (Q.lp_have ? 1.0 : 0.0) + 2.0 * (double)Q.lp_age; u[7 * WAVE + lane] = Q.lp_good ? 1.0 : 0.0;
+  u[6 * WAVE + lane] = (Q.lp_have ? 1.0 : 0.0) + 2.0 * (double)Q.lp_age;
+  // (row 7: lp_good, and in lanes 1, 2 the fourth and fifth tap - everything here is uniform over the wavefront)
+  double r7 = Q.lp_good ? 1.0 : 0.0;
+  if constexpr (NC == 5) r7 = lane == 1 ? Q.lpa[3] : lane == 2 ? Q.lpa[4] : r7;
+  u[7 * WAVE + lane] = r7;
 }
-template <typename T>
-__device__ __forceinline__ void ms_pred_load(MsPred<T>& Q, const double* img, int lane) {
+template <typename T, int NC>
+__device__ __forceinline__ void ms_pred_load(MsPred<T, NC>& Q, const double* img, int lane) {
 #pragma unroll
   for (int q = 0; q < MS_EPL; ++q)
 #pragma unroll
@@ -1090,12 +1174,13 @@ __device__ __forceinline__ void ms_pred_load(MsPred<T>& Q, const double* img, in
   const int hv = __builtin_amdgcn_readfirstlane((int)u[6 * WAVE + lane]);
   Q.lp_have = (hv & 1) != 0;
   Q.lp_age = hv >> 1;
-  Q.lp_good = __builtin_amdgcn_readfirstlane((int)u[7 * WAVE + lane]) != 0;
+  Q.lp_good = __builtin_amdgcn_readfirstlane((int)u[7 * WAVE + 0]) != 0;
+  if constexpr (NC == 5) { Q.lpa[3] = u[7 * WAVE + 1]; Q.lpa[4] = u[7 * WAVE + 2]; }
 }
 
 // writes the start values of the coming step into Xs (boundary rows of interval 0 from the cold table)
-template <typename T>
-__device__ __forceinline__ void ms_pred_guess(const MsPred<T>& Q, int order, int lane, const T* cold, T* Xs) {
+template <typename T, int NC>
+__device__ __forceinline__ void ms_pred_guess(const MsPred<T, NC>& Q, int order, int lane, const T* cold, T* Xs) {
 #pragma unroll
       for (int q = 0; q < MS_EPL; ++q) {
         const int e = lane + q * WAVE;
@@ -1103,8 +1188,9 @@ __device__ __forceinline__ void ms_pred_guess(const MsPred<T>& Q, int order, int
           const int i = e / 19, r = e - i * 19;
           T g;
           if (order == MS_ORDER_LP) {
-            const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
-            g = (T)(Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2));
+            double b[NC];
+            lp_basis<T, NC>(Q.Hx[q], b);
+            g = (T)lp_eval<NC>(Q.lpa, b);
           } else {
             g = extrapolate_n<T>(order, Q.Hx[q]);
           }
@@ -1119,8 +1205,8 @@ __device__ __forceinline__ void ms_pred_guess(const MsPred<T>& Q, int order, int
 
 // after a step: which predictor would have predicted it best (-> Q.next_order), refit the linear
 // predictor, shift the time levels.  `order` is what the step just solved started from.
-template <typename T>
-__device__ __forceinline__ void ms_pred_update(MsPred<T>& Q, int order, int status, int predictor, int lane,
+template <typename T, int NC>
+__device__ __forceinline__ void ms_pred_update(MsPred<T, NC>& Q, int order, int status, int predictor, int lane,
                                                const T* Xs, MsStamps& stamps) {
     // ---- extrapolation order of the next step: the one that would have predicted this step best ----
     // (smooth inputs climb to the highest order; after a jump in the controls the low orders win
@@ -1155,8 +1241,9 @@ __device__ __forceinline__ void ms_pred_update(MsPred<T>& Q, int order, int stat
           const int e = lane + q * WAVE;
           if (e < MS_NE) {
             const double x = (double)Xs[e];
-            const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
-            err_lp = fmaxf(err_lp, update_ratio(x - (Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2)), x));
+            double b[NC];
+            lp_basis<T, NC>(Q.Hx[q], b);
+            err_lp = fmaxf(err_lp, update_ratio(x - lp_eval<NC>(Q.lpa, b), x));
           }
         }
       }
@@ -1167,42 +1254,27 @@ __device__ __forceinline__ void ms_pred_update(MsPred<T>& Q, int order, int stat
       const bool keep_fit = lp_tested && em_lp < 1.0e-3f && Q.lp_age < 3 && status == KR_ST_CONVERGED;
       Q.lp_age = keep_fit ? Q.lp_age + 1 : 0;
       Q.lp_have = keep_fit;
-      if (!keep_fit && predictor >= MS_ORDER_LP && Q.avail >= 2 && status == KR_ST_CONVERGED) {
-        double Sn[9];
+      if (!keep_fit && predictor >= MS_ORDER_LP && Q.avail >= NC - 1 && status == KR_ST_CONVERGED) {
+        double Sn[lp_nsum<NC>()];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
+        for (int k = 0; k < lp_nsum<NC>(); ++k) Sn[k] = 0.0;
 #pragma unroll
         for (int q = 0; q < MS_EPL; ++q) {
           const int e = lane + q * WAVE;
           if (e < MS_NE) {
             const double x = (double)Xs[e];
-            const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+            double b[NC];
+            lp_basis<T, NC>(Q.Hx[q], b);
             const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
-            const double w0 = h0 * w, w1 = (h0 - h1) * w, w2 = (h0 - 2.0 * h1 + h2) * w, xw = x * w;
-            Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
-            Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
+            lp_accumulate<NC>(Sn, b, x, w);
           }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Sn[k] = wave_sum_f64(Sn[k]);
-        // (N + lam diag N) a = r + lam diag(N) 1: ridge towards quadratic extrapolation, relative per column
-        const double lam = 1e-12;
-        double a6[3][4] = {{Sn[0] * (1 + lam), Sn[1], Sn[2], Sn[6] + lam * Sn[0]},
-                           {Sn[1], Sn[3] * (1 + lam), Sn[4], Sn[7] + lam * Sn[3]},
-                           {Sn[2], Sn[4], Sn[5] * (1 + lam), Sn[8] + lam * Sn[5]}};
-        // symmetric positive definite: elimination without pivoting
-        const double i0 = fast_rcp(a6[0][0]);
-        const double f1 = a6[1][0] * i0, f2 = a6[2][0] * i0;
+        for (int k = 0; k < lp_nsum<NC>(); ++k) Sn[k] = wave_sum_f64(Sn[k]);
+        double a[NC];
+        if (lp_solve<NC>(Sn, a)) {
 #pragma unroll
-        for (int c = 1; c < 4; ++c) { a6[1][c] -= f1 * a6[0][c]; a6[2][c] -= f2 * a6[0][c]; }
-        const double i1 = fast_rcp(a6[1][1]);
-        const double f3 = a6[2][1] * i1;
-        a6[2][2] -= f3 * a6[1][2]; a6[2][3] -= f3 * a6[1][3];
-        const double x2 = a6[2][3] * fast_rcp(a6[2][2]);
-        const double x1 = (a6[1][3] - a6[1][2] * x2) * i1;
-        const double x0 = (a6[0][3] - a6[0][1] * x1 - a6[0][2] * x2) * i0;
-        if (isfinite(x0) && isfinite(x1) && isfinite(x2) && fabs(x0) < 4.0 && fabs(x1) < 16.0 && fabs(x2) < 64.0) {
-          Q.lpa[0] = x0; Q.lpa[1] = x1; Q.lpa[2] = x2;
+          for (int k = 0; k < NC; ++k) Q.lpa[k] = a[k];
           Q.lp_have = true;
         }
       }
@@ -1292,7 +1364,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
     // kr_simulate_batch, one launch per step: the predictor of the persistent kernel, carried from launch to
     // launch through its image in HBM
     double* img = A.pred + (size_t)rod * MS_PRED_ROWS * WAVE;
-    MsPred<T> Q;
+    MsPred<T, NN ? 5 : 3> Q;
     if (A.pred_reset) ms_pred_init<T>(Q, lane, R, A.cur + rod * rod_elems, A.prev + rod * rod_elems, A.pred_has_prev != 0, A.pred_limit);
     else ms_pred_load<T>(Q, img, lane);
     S.kappa = Q.kappa;
@@ -1393,7 +1465,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
       for (int c = 0; c < 12; ++c) regP[q][c] = T(0);
     }
   }
-  MsPred<T> Q;
+  MsPred<T, NN ? 5 : 3> Q;
   double* img = A.pred_io ? A.pred_io + (size_t)rod * MS_PRED_ROWS * WAVE : nullptr;
   if (img && A.pred_load && !resumed) ms_pred_load<T>(Q, img, lane);
   else ms_pred_init<T>(Q, lane, R, s0, sp, resumed || A.prev_init != nullptr, A.predictor);

@@ -282,8 +282,8 @@ __device__ __forceinline__ float msw_residual_local(const T* Es, const T* Xs, co
 }
 
 // ---- predictor of one wavefront's unknowns (NE = K x 19 entries of Xs starting at interval g0) -------------------
-template <typename T>
-__device__ __forceinline__ void mswp_init(MsPred<T>& Q, int lane, int ne, int g0, int N, int P, const T* s0, const T* sp,
+template <typename T, int NC>
+__device__ __forceinline__ void mswp_init(MsPred<T, NC>& Q, int lane, int ne, int g0, int N, int P, const T* s0, const T* sp,
                                           bool has_prev, int predictor) {
 #pragma unroll
   for (int q = 0; q < MS_EPL; ++q) {
@@ -294,7 +294,8 @@ __device__ __forceinline__ void mswp_init(MsPred<T>& Q, int lane, int ne, int g0
 #pragma unroll
     for (int k = 1; k < MS_HLEV; ++k) Q.Hx[q][k] = sp[off];
   }
-  Q.lpa[0] = Q.lpa[1] = Q.lpa[2] = 1.0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) Q.lpa[k] = 1.0;
   Q.lp_have = Q.lp_good = false;
   Q.lp_age = 0;
   Q.avail = has_prev ? 1 : 0;
@@ -302,8 +303,8 @@ __device__ __forceinline__ void mswp_init(MsPred<T>& Q, int lane, int ne, int g0
   if (Q.next_order >= MS_HLEV) Q.next_order = MS_HLEV - 1;
   Q.kappa = T(0);
 }
-template <typename T>
-__device__ __forceinline__ void mswp_guess(const MsPred<T>& Q, int order, int lane, int ne, bool first, const T* cold, T* Xl) {
+template <typename T, int NC>
+__device__ __forceinline__ void mswp_guess(const MsPred<T, NC>& Q, int order, int lane, int ne, bool first, const T* cold, T* Xl) {
 #pragma unroll
   for (int q = 0; q < MS_EPL; ++q) {
     const int e = lane + q * WAVE;
@@ -311,8 +312,9 @@ __device__ __forceinline__ void mswp_guess(const MsPred<T>& Q, int order, int la
       const int i = e / 19, r = e - i * 19;
       T g;
       if (order == MS_ORDER_LP) {
-        const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
-        g = (T)(Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2));
+        double b[NC];
+        lp_basis<T, NC>(Q.Hx[q], b);
+        g = (T)lp_eval<NC>(Q.lpa, b);
       } else {
         g = extrapolate_n<T>(order, Q.Hx[q]);
       }
@@ -325,8 +327,8 @@ __device__ __forceinline__ void mswp_guess(const MsPred<T>& Q, int order, int la
   }
 }
 // ms_pred_update with its decisions reduced over the W wavefronts of the rod
-template <typename T, int W>
-__device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status, int predictor, int lane, int wave, int ne,
+template <typename T, int W, int NC>
+__device__ __forceinline__ void mswp_update(MsPred<T, NC>& Q, int order, int status, int predictor, int lane, int wave, int ne,
                                             const T* Xl, T* redT) {
   float* redf = reinterpret_cast<float*>(redT);
   double* redd = reinterpret_cast<double*>(redT);  // (W * 32 elements of T >= W doubles)
@@ -352,8 +354,9 @@ __device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status,
       const int e = lane + q * WAVE;
       if (e < ne) {
         const double x = (double)Xl[e];
-        const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
-        err_lp = fmaxf(err_lp, update_ratio(x - (Q.lpa[0] * h0 + Q.lpa[1] * (h0 - h1) + Q.lpa[2] * (h0 - 2.0 * h1 + h2)), x));
+        double b[NC];
+        lp_basis<T, NC>(Q.Hx[q], b);
+        err_lp = fmaxf(err_lp, update_ratio(x - lp_eval<NC>(Q.lpa, b), x));
       }
     }
   }
@@ -362,39 +365,41 @@ __device__ __forceinline__ void mswp_update(MsPred<T>& Q, int order, int status,
   const bool keep_fit = lp_tested && em_lp < 1.0e-3f && Q.lp_age < 3 && status == KR_ST_CONVERGED;
   Q.lp_age = keep_fit ? Q.lp_age + 1 : 0;
   Q.lp_have = keep_fit;
-  if (!keep_fit && predictor >= MS_ORDER_LP && Q.avail >= 2 && status == KR_ST_CONVERGED) {
-    double Sn[9];
+  if (!keep_fit && predictor >= MS_ORDER_LP && Q.avail >= NC - 1 && status == KR_ST_CONVERGED) {
+    double Sn[lp_nsum<NC>()];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Sn[k] = 0.0;
+    for (int k = 0; k < lp_nsum<NC>(); ++k) Sn[k] = 0.0;
 #pragma unroll
     for (int q = 0; q < MS_EPL; ++q) {
       const int e = lane + q * WAVE;
       if (e < ne) {
         const double x = (double)Xl[e];
-        const double h0 = (double)Q.Hx[q][0], h1 = (double)Q.Hx[q][1], h2 = (double)Q.Hx[q][2];
+        double b[NC];
+        lp_basis<T, NC>(Q.Hx[q], b);
         const double w = (double)__builtin_amdgcn_rcpf(fmaxf(fabsf((float)x), 1.0f));
-        const double w0 = h0 * w, w1 = (h0 - h1) * w, w2 = (h0 - 2.0 * h1 + h2) * w, xw = x * w;
-        Sn[0] += w0 * w0; Sn[1] += w0 * w1; Sn[2] += w0 * w2; Sn[3] += w1 * w1; Sn[4] += w1 * w2; Sn[5] += w2 * w2;
-        Sn[6] += w0 * xw; Sn[7] += w1 * xw; Sn[8] += w2 * xw;
+        lp_accumulate<NC>(Sn, b, x, w);
       }
     }
-    msw_sum_n<W, 9>(Sn, redd, wave, lane);
-    const double lam = 1e-12;
-    double a6[3][4] = {{Sn[0] * (1 + lam), Sn[1], Sn[2], Sn[6] + lam * Sn[0]},
-                       {Sn[1], Sn[3] * (1 + lam), Sn[4], Sn[7] + lam * Sn[3]},
-                       {Sn[2], Sn[4], Sn[5] * (1 + lam), Sn[8] + lam * Sn[5]}};
-    const double i0 = fast_rcp(a6[0][0]);
-    const double f1 = a6[1][0] * i0, f2 = a6[2][0] * i0;
+    if constexpr (lp_nsum<NC>() <= 16) {
+      msw_sum_n<W, lp_nsum<NC>()>(Sn, redd, wave, lane);
+    } else {  // (the reduction scratch holds 16 doubles per wavefront: matrix and right-hand side one after the other)
+      constexpr int NM = NC * (NC + 1) / 2;
+      double Sa[NM], Sb[NC];
 #pragma unroll
-    for (int c = 1; c < 4; ++c) { a6[1][c] -= f1 * a6[0][c]; a6[2][c] -= f2 * a6[0][c]; }
-    const double i1 = fast_rcp(a6[1][1]);
-    const double f3 = a6[2][1] * i1;
-    a6[2][2] -= f3 * a6[1][2]; a6[2][3] -= f3 * a6[1][3];
-    const double x2 = a6[2][3] * fast_rcp(a6[2][2]);
-    const double x1 = (a6[1][3] - a6[1][2] * x2) * i1;
-    const double x0 = (a6[0][3] - a6[0][1] * x1 - a6[0][2] * x2) * i0;
-    if (isfinite(x0) && isfinite(x1) && isfinite(x2) && fabs(x0) < 4.0 && fabs(x1) < 16.0 && fabs(x2) < 64.0) {
-      Q.lpa[0] = x0; Q.lpa[1] = x1; Q.lpa[2] = x2;
+      for (int k = 0; k < NM; ++k) Sa[k] = Sn[k];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) Sb[k] = Sn[NM + k];
+      msw_sum_n<W, NM>(Sa, redd, wave, lane);
+      msw_sum_n<W, NC>(Sb, redd, wave, lane);
+#pragma unroll
+      for (int k = 0; k < NM; ++k) Sn[k] = Sa[k];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) Sn[NM + k] = Sb[k];
+    }
+    double a[NC];
+    if (lp_solve<NC>(Sn, a)) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) Q.lpa[k] = a[k];
       Q.lp_have = true;
     }
   }
@@ -1315,7 +1320,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   }
   const int ne = R.K * 19;
   T* Xl = L.Xs + R.g0 * 19;
-  MsPred<T> Q;
+  MsPred<T, NN ? 5 : 3> Q;
   double* img = A.pred_io ? A.pred_io + ((size_t)rod * W + wave) * MS_PRED_ROWS * WAVE : nullptr;
   if (img && A.pred_load) ms_pred_load<T>(Q, img, lane);
   else mswp_init<T>(Q, lane, ne, R.g0, N, P, s0, sp, A.prev_init != nullptr, A.predictor);

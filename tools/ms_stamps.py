@@ -15,6 +15,14 @@ dev = "cuda:0"; dt = torch.float64
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
 if NN:
     mlp = orc.make_mlp([28, 64, 64, 25], "elu", seed=7)
+    if os.environ.get("KR_STAMP_BF16W"):  # probe: weights exactly representable in bf16 (the JVP operands then carry no rounding)
+        def bf16r(a):
+            u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+            u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+            return u.view(np.float32)
+        mlp.weights = [bf16r(w) for w in mlp.weights]
+    if os.environ.get("KR_STAMP_PBLIND"):  # probe: a network that does not read p (the condensed Jacobian has no columns for p)
+        mlp.weights[0] = mlp.weights[0].copy(); mlp.weights[0][:, 0:3] = 0.0
     model, params = [], []
     for W_, b_, a_ in zip(mlp.weights, mlp.biases, mlp.acts):
         model.append("Linear"); params += [W_, b_]
