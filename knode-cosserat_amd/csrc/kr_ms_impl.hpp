@@ -149,6 +149,7 @@ enum : int {
   CD_KSEI = 34, CD_KSEV = 43, CD_BSE = 46, CD_KBTI = 55, CD_BBT = 64, CD_SIZE = 76
 };
 // LDS elements of one rod (a multiple of 4, so every rod's slice stays 16-byte aligned)
+constexpr int MS_BP_ELEMS = 3 * 3 * 19 + 1 + 12;  // [interval 1..3][p direction][19 rows], padding, [3][3] p updates (+3)
 template <typename T, int HS>
 __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = false) {
   // XB, Tm, Es are contiguous; with the MLP on the same region doubles as the 64 x 32 exchange
@@ -158,6 +159,7 @@ __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = fa
   alg = (alg + 3) & ~size_t(3);
   size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + 40 + alg;  // 40: Ti (6 x 6 inverse)
   if (persist) n += (size_t)N * 12;
+  if (persist && nn) n = ((n + 3) & ~size_t(3)) + MS_BP_ELEMS;  // p-column blocks B_g (ms_newton)
   return (n + 3) & ~size_t(3);
 }
 
@@ -273,6 +275,7 @@ struct MsLds {
   T* cold;  // [CD_SIZE]       per-step parameters (see ms_cold_fill)
   T* Ti;    // [6][6]          inverse of the condensed 6x6 matrix of the last full Newton update (chord check)
   T* c12;   // persistent kernel only: [N][12] leading slots (q w v u) of the newest state
+  T* Bp;    // persistent kernel with the MLP on: p-column blocks [3][3][19] (+ scratch), see ms_newton
 };
 template <typename T, int HS>
 __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist, bool nn = false) {
@@ -288,6 +291,7 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist, bool 
   size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);  // as in ms_lds_elems
   if (nn && alg < mj_scratch_elems<T>()) alg = mj_scratch_elems<T>();
   L.c12 = persist ? L.XB + ((alg + 3) & ~size_t(3)) : nullptr;
+  L.Bp = (persist && nn) ? L.c12 + (((size_t)N * 12 + 3) & ~size_t(3)) : nullptr;
   return L;
 }
 
@@ -305,6 +309,7 @@ struct MsSolveArgs {
   // of every record, [N][12] in LDS (nullptr: nowhere)
   T* lead12 = nullptr;
   bool quick_ok = true;  // option "residual_test": the residual test below may accept a storing sweep
+  int prot = 0;          // persistent kernel with the MLP on: sweeps so far (which intervals the p-column lanes serve)
 };
 
 // Scaled maximum norm of the residual of a sweep - the interface jumps E_g - Y_{g+1} (19 rows each) and the tip
@@ -358,23 +363,66 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
   const int r = 3 + (lane >> 2);
   // update norm per unit of residual norm, measured at the last full Newton update of this solve (<= 0: unknown)
   float amp = -1.f;
+  // ---- p columns (persistent kernel, MLP on) ----------------------------------------------------------------------
+  // The physics does not read p, so the condensed Jacobian carries no columns for the start positions of the intervals
+  // 1..3: dE_g/dp_g is the identity.  The network DOES read p, and what it adds, B_g = dE_g/dp_g - [I; 0] (19 x 3), was
+  // what held the iteration at a contraction of 1e-3 per sweep (the slowest rods of BASELINE cfg3 needed a fourth
+  // sweep for it).  Nine more trajectories do not fit a wavefront (58 + 9 lanes), so the six
+  // spare lanes integrate the p columns of TWO intervals per sweep, in rotation; B_g lives in LDS across sweeps and
+  // time steps (it only corrects the Jacobian: a block one or two sweeps old is accurate to a few per cent, which puts
+  // the contraction at ~1e-5), their network evaluations ride on the free columns 6..14 of sample tile 0, and the
+  // Newton update gets one step of defect correction, d = d0 + Jt^-1 (B dp0), through the factors just computed.
+  constexpr bool PCOL = NN && PERSIST && SCHEME == KR_EULER;
+  const bool pl = PCOL && idle;                     // lanes 58..63
+  const int pslot = lane - (7 + 17 * (MS_P - 1));   // 0..5 on those lanes
+  T* Bp = L.Bp;
 
   while (true) {
+    // ---- role of the spare lanes in this sweep ------------------------------
+    int iv_l = iv, s_l = R.s_i, len_l = R.len_i, pc = 0, pg = 0;
+    SweepCtx<T, HS> Cl = C;
+    if constexpr (PCOL) {
+      const int rot = S.prot % 3;  // intervals served: (1, 2), (3, 1), (2, 3)
+      const int ga = rot == 0 ? 1 : rot == 1 ? 3 : 2, gb = rot == 0 ? 2 : rot == 1 ? 1 : 3;
+      const int gu = 6 - ga - gb;  // the interval nobody serves this sweep
+      S.prot += 1;
+      Cl.role.ptab = true;
+      if (pl) {
+        pg = pslot < 3 ? ga : gb;
+        pc = pslot < 3 ? pslot : pslot - 3;
+        iv_l = pg;
+        s_l = ms_interval_start(pg, R.sbase, R.srem);
+        len_l = R.sbase + (pg < R.srem ? 1 : 0);
+        Cl.role.iv = pg; Cl.role.col = 1; Cl.role.idle = false;
+        Cl.role.xrow = 6 + 3 * (pg - 1) + pc;
+      } else if (col == 0) {
+        // (the unperturbed lanes zero the dx rows of sample tile 0 nobody owns: the unserved interval's three, and row 15)
+        Cl.role.zrow = iv < 3 ? 6 + 3 * (gu - 1) + iv : 15;
+      }
+    }
     // ---- start state of this lane ------------------------------------------
     T yr[19];
 #pragma unroll
-    for (int r = 0; r < 19; ++r) yr[r] = Xs[iv * MS_YP + r];
+    for (int r = 0; r < 19; ++r) yr[r] = Xs[iv_l * MS_YP + r];
     // forward-difference step of this lane's column (one LDS read at the lane's own component instead of a
     // 16-way select over the registers, which the compiler also re-derived after the sweep)
     const T hstep = col > 0 ? S.fd_eps * fmax(fabs(Xs[iv * MS_YP + (R.comp > 0 ? R.comp : 3)]), T(1)) : T(1);
 #pragma unroll
     for (int r = 3; r < 19; ++r) yr[r] += r == R.comp ? hstep : T(0);
+    T hp = T(1);
+    if constexpr (PCOL) {
+      if (pl) {
+        hp = S.fd_eps * fmax(fabs(Xs[pg * MS_YP + pc]), T(1));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) yr[r] += r == pc ? hp : T(0);
+      }
+    }
     RodState<T> y = rows_to_state(yr);
     const bool st = (storing || flush) && col == 0 && !idle;
 
     // ---- sweep over this lane's sub-interval --------------------------------
     T hv[HS];
-    load_hist_vec<T, HS>(C.hbase + (size_t)R.s_i * HS, hv);
+    load_hist_vec<T, HS>(C.hbase + (size_t)s_l * HS, hv);
     // one grid point: evaluate, (on the accepted sweep, unperturbed lanes) stream the record out, advance.
     // STORE is a compile-time tag so that the other sweeps run a branch-free body the scheduler can
     // overlap across consecutive grid points.
@@ -382,7 +430,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       constexpr bool STORE = decltype(store_tag)::value;
       RodState<T> k1;
       V3<T> v, u;
-      eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, C, y, hv, k1, v, u);
+      eval_point<T, DIAG, NN, HS, PERSIST>(Pc, M, Cl, y, hv, k1, v, u);
       if constexpr (STORE) {
         if (st && live) {
           T rec[KR_SLOTS];
@@ -424,8 +472,8 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       // with the MLP on every lane must reach the wave-wide matrix-core call: lanes past the end of
       // their (shorter) interval keep running on the last grid point and simply do not commit
       for (int t = 0; t < R.lmax; ++t) {
-        const bool live = t < R.len_i;
-        const int j = live ? R.s_i + t : R.s_i + R.len_i - 1;
+        const bool live = t < len_l;
+        const int j = live ? s_l + t : s_l + len_l - 1;
         const RodState<T> y_in = y;
         if (storing || flush) point(std::true_type{}, j, live);  // wave-uniform choice
         else point(std::false_type{}, j, true);
@@ -492,6 +540,14 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     // 39 x the estimate (median 12).  With a safety factor of 256 the sweep is accepted without any condensation
     // when the predicted update is below the tolerance - in the two-sweep regime the actual update is ~1e-12 against
     // a tolerance of 1e-8, so the factor costs nothing there.  Otherwise the chord check decides as before.
+    // defect correction for the p columns (PCOL): first pass = the update of the condensed system, second pass = the same
+    // factors applied to B dp of the first
+    bool pcorr = false;
+    T d1[6], updY1[MS_P - 1], updP1 = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d1[k] = T(0);
+#pragma unroll
+    for (int g = 0; g < MS_P - 1; ++g) updY1[g] = T(0);
     bool quick = false;
     float quick_est = 0.f;
     if (!NN && S.quick_ok && chord && amp > 0.f) {  // (with the MLP on the Jacobian is approximate and the ratio not audited)
@@ -524,7 +580,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       T* ach = XB;             // a_g, g = 1 .. P-1: [g][19]
       T* rt = XB + 4 * MS_YP;  // tip right-hand side [6]
       dYb = XB + MS_YP * 8;
-      {
+      if (!pcorr) {
         T er[19];
         state_to_rows(y, er);
         if (col == 0 && !idle) {
@@ -605,6 +661,18 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
           __builtin_amdgcn_sched_barrier(0);
   #pragma unroll
           for (int r = 0; r < 19; ++r) Es[lane * MS_YP + r] = (er[r] - e0[r]) * ih;
+        }
+        if constexpr (PCOL) {
+          if (pl) {  // column pc of B_pg = dE/dp - [I; 0]
+            const T ihp = fast_rcp(hp);
+            const int l0p = 7 + 17 * (pg - 1);
+            T e0[19];
+  #pragma unroll
+            for (int r = 0; r < 19; ++r) e0[r] = Es[l0p * MS_YP + r];
+            __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+            for (int r = 0; r < 19; ++r) Bp[((pg - 1) * 3 + pc) * 19 + r] = (er[r] - e0[r]) * ihp - (r == pc ? T(1) : T(0));
+          }
         }
         wave_sync();
       }
@@ -746,6 +814,14 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     // iteration (stop test, contraction estimate), so it is formed in fp32 with the hardware reciprocal.
     dnf = 0.f;
     updP = T(0); updG = T(0); xsP = T(0); xsG = T(0);
+    if constexpr (PCOL) {
+      if (pcorr) {  // second pass: what was computed above is the correction - add the update of the first pass
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] += d1[k];
+#pragma unroll
+        for (int g = 0; g < MS_P - 1; ++g) updY[g] += updY1[g];
+      }
+    }
     if (plane) {  // this lane owns Y_{pi+1}[prow]
       xsP = Xs[(pi + 1) * MS_YP + prow];
 #pragma unroll
@@ -753,6 +829,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
         const T t = sp[i * 3 + prow];
         updP += i <= pi ? t : T(0);
       }
+      if constexpr (PCOL) updP += pcorr ? updP1 : T(0);
       dnf = update_ratio(updP, xsP);
     }
     if (glane) {
@@ -771,6 +848,44 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     }
     dnf = wave_max_nonneg(dnf);  // +inf if any update is not finite
     finite = dnf <= 3.0e38f;
+    if constexpr (PCOL) {
+      if (!pcorr && !chord && finite) {
+        // ---- defect correction for the p columns ------------------------------------------------------------
+        // The update above solves the system WITHOUT the blocks B_g.  With them, dY_{g+1} = c_g + A_g dY_g + B_g dY_g[p]:
+        // the difference satisfies the same recursion with "residuals" c'_g = B_g dY_g[p] (c'_0 = 0) and a homogeneous
+        // tip condition, which is exactly what the chord branch solves from the base end-state slots of Es - so those
+        // slots are rewritten as Y_{g+1} + c'_g (tip rows: F_tip + c'_3) and the loop goes round once more.  One step
+        // of this leaves an error of (1e-3)^2 of the update.
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d1[k] = d[k];
+#pragma unroll
+        for (int g = 0; g < MS_P - 1; ++g) updY1[g] = updY[g];
+        updP1 = updP;
+        T* dPl = Bp + 3 * 3 * 19 + 1;  // [interval 1..3][3]: p update of the first pass
+        if (plane) dPl[pi * 3 + prow] = updP;
+        wave_sync();
+        if (lane < 19) {
+#pragma unroll
+          for (int g = 0; g < MS_P; ++g) {
+            const int l0 = g == 0 ? 0 : 7 + 17 * (g - 1);
+            T cp = T(0);
+            if (g > 0) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) cp = fma(Bp[((g - 1) * 3 + c) * 19 + lane], dPl[(g - 1) * 3 + c], cp);
+            }
+            T basev;
+            if (g < MS_P - 1) basev = Xs[(g + 1) * MS_YP + lane];
+            else basev = (lane >= 7 && lane < 13) ? L.cold[CD_FTIP + (lane - 7)] : T(0);
+            Es[l0 * MS_YP + lane] = basev + cp;
+          }
+        }
+        wave_sync();
+        pcorr = true;
+        chord = true;
+        continue;
+      }
+      if (pcorr) break;  // (the second pass is a correction, not a chord check: nothing to be conclusive about)
+    }
     if (chord && !(finite && (T)dnf <= T(0.5) * S.tol)) {
       chord = false;  // not conclusive: compute the Newton update proper
       continue;
@@ -1443,6 +1558,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   const MsLds<T> L = ms_carve<T, HS>(reinterpret_cast<T*>(smem_raw) + (size_t)wv * ms_lds_elems<T, HS>(N, true, NN), N, true, NN);
   const MsRole R = ms_role(lane, N);
   ms_cold_fill<T>(Pc, L.cold, lane);
+  if constexpr (NN) {  // p-column blocks of the Jacobian (ms_newton): none known yet
+    for (int e = lane; e < MS_BP_ELEMS; e += WAVE) L.Bp[e] = T(0);
+  }
   wave_sync();
 
   // leading slots (q w v u) of the newest state live in LDS (c12), those of the state before it in

@@ -238,6 +238,8 @@ struct NnRole {
   int iv = 0, col = 0;
   bool idle = false, jvp = false;
   int zrow = -1;  // dx row a lane without a column zeroes (-1: the layout of the one-wavefront kernels)
+  int xrow = -1;  // dx row of a lane with a column, when it is not 16 iv + col - 1 (p columns)
+  bool ptab = false;  // wavefront-uniform: columns 6..14 of sample tile 0 carry p columns (mlp_jvp.hpp, jvp_scale_pack)
 };
 // JVP_ONLY: the caller guarantees M.mfma_ok && M.jvp_ok and a lane role (kr_msw_impl.hpp with the MLP on) - no other
 // evaluator is compiled in, so that the register limit of a two-wavefronts-per-SIMD kernel holds for all its callees
@@ -256,9 +258,9 @@ __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB,
       x[25] = tf.x; x[26] = tf.y; x[27] = tf.z;
       T d[25];
       if constexpr (JVP_ONLY) {
-        mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d);
+        mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d, role.xrow, role.ptab);
       } else {
-        if (role.jvp && M.jvp_ok) mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d);  // wave-uniform choice
+        if (role.jvp && M.jvp_ok) mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d, role.xrow, role.ptab);  // wave-uniform choice
         else mlp_mfma_eval<T>(M, x, tile, lane, d);
       }
       T yr2[19];

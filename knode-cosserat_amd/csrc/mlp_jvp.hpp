@@ -76,6 +76,7 @@ struct JvpNet {
   const bf16x8* j[3];       // JVP chain: bf16 A fragments [tile][k-step of 32][lane]
   int kg[3], ot[3], jks[3]; // k-groups (of 16 inputs) per tile, 16-unit tiles, JVP k-steps
   int L;
+  int ptab;                 // columns 6..14 of sample tile 0 are p columns of the intervals 1..3 (jvp_scale_pack)
 };
 template <typename T>
 __device__ __forceinline__ JvpNet jvp_net(const MlpDev<T>& M) {
@@ -86,6 +87,7 @@ __device__ __forceinline__ JvpNet jvp_net(const MlpDev<T>& M) {
     n.kg[k] = M.kgroups[k]; n.ot[k] = M.otiles[k]; n.jks[k] = M.jksteps[k];
   }
   n.L = M.n_layers;
+  n.ptab = 0;
   return n;
 }
 
@@ -195,13 +197,20 @@ __device__ __forceinline__ void jvp_accumulate(f32x4 (&dst)[NO][4], const bf16x8
 }
 // D tiles of a 64-unit hidden chunk (4 unit tiles x 4 sample tiles) -> scaled by act' of the tile's interval ->
 // bf16 B operands of the next layer (2 k-steps of 32 units)
-__device__ __forceinline__ void jvp_scale_pack(const f32x4 (&dh)[4][4], const MJ_LDS float* actp, int lane, bf16x8 (&b)[4][2]) {
+// Sample tile 0 holds the 6 columns of interval 0; its columns 6..14 may carry three extra samples for each of the
+// intervals 1..3 (the p columns of kr_ms_impl.hpp: perturbations of an interval's start position, which only the network
+// reads) - a lane's column is fixed, so it simply takes the act' table of the interval its column belongs to.
+__device__ __forceinline__ void jvp_scale_pack(const f32x4 (&dh)[4][4], const MJ_LDS float* actp, int lane, bf16x8 (&b)[4][2],
+                                               int ptab) {
   const int q = lane >> 4;
+  const int c0 = lane & 15;
+  const int tbl0 = (ptab && c0 >= 6 && c0 < 15) ? 1 + (c0 - 6) / 3 : 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     f32x4 g[4];
+    const int tbl = s == 0 ? tbl0 : s;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) g[o] = *reinterpret_cast<const MJ_LDS f32x4*>(actp + s * 64 + 16 * o + 4 * q);
+    for (int o = 0; o < 4; ++o) g[o] = *reinterpret_cast<const MJ_LDS f32x4*>(actp + tbl * 64 + 16 * o + 4 * q);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -244,6 +253,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
     kgs[k] = uni(netv.kg[k]); ots[k] = uni(netv.ot[k]); jkss[k] = uni(netv.jks[k]);
   }
   const int L = uni(netv.L);
+  const int ptab = uni(netv.ptab);
   MJ_LDS unsigned char* sbase = (MJ_LDS unsigned char*)(unsigned)__builtin_amdgcn_readfirstlane(
       (int)(unsigned long long)(MJ_LDS unsigned char*)scratch_generic);
   MJ_LDS T* xb = (MJ_LDS T*)sbase;
@@ -318,7 +328,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
       jvp_accumulate<4, 1>(dh, a1, bdx);
       mm_wave_sync();
       bf16x8 b1[4][2];
-      jvp_scale_pack(dh, actp, lane, b1);
+      jvp_scale_pack(dh, actp, lane, b1, ptab);
       mm_wave_sync();  // (actp is rewritten by the next chunk)
       jvp_accumulate<MM_OUT_T, 2>(ojvp, ao, b1);
     }
@@ -370,7 +380,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
       zero_dh(dh);
       jvp_accumulate<4, 1>(dh, a1, bdx);
       MJ_STAMP(6);  // JVP layer 1
-      jvp_scale_pack(dh, actp, lane, b1);
+      jvp_scale_pack(dh, actp, lane, b1, ptab);
       MJ_STAMP(7);  // scale + pack 1
     }
 #pragma unroll 1
@@ -384,7 +394,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
       jvp_accumulate<4, 2>(dh, a2, b1);
       MJ_STAMP(8);  // JVP layer 2
       bf16x8 b2[4][2];
-      jvp_scale_pack(dh, actp + (1 + ch) * 256, lane, b2);
+      jvp_scale_pack(dh, actp + (1 + ch) * 256, lane, b2, ptab);
       MJ_STAMP(9);  // scale + pack 2
       jvp_accumulate<MM_OUT_T, 2>(ojvp, ao, b2);
       MJ_STAMP(10);  // JVP output layer
@@ -408,10 +418,11 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
 // Per-lane wrapper.  iv / col: the lane's role (sub-interval of the wavefront 0..3, 0 = unperturbed); idle lanes pass
 // col = 0 and a copy of their interval's state.  zrow: the dx row a lane without a column zeroes (the rows no column
 // owns: every sample tile has 16, an interval 6 or 16 columns; -1 = lane layout 7 + 3 x 17 of kr_ms_impl.hpp).
+// xrow: the dx / J dx row of a lane with a column when it is not 16 iv + col - 1 (the p columns in sample tile 0).
 // x in, NN(x) (base lanes) or NN(x_base) + J dx (the others) out.
 template <typename T, int VAR = 0>
 __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
-                                             bool idle, int zrow, T (&out)[25]) {
+                                             bool idle, int zrow, T (&out)[25], int xrow = -1, bool ptab = false) {
   using V = typename MjVec<T>::type;
   constexpr int n = MjVec<T>::n;
   T* xb = scratch;
@@ -433,7 +444,7 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
   // inside divergent control flow there has produced wrong reloads (hipcc 7.2, fp64, kr_msw_impl.hpp with the MLP on).
   {
     const bool has = col > 0;
-    const int row = has ? 16 * iv + col - 1 : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
+    const int row = has ? (xrow >= 0 ? xrow : 16 * iv + col - 1) : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
     float d[MM_IN];
     const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);
 #pragma unroll
@@ -460,7 +471,8 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
     }
   }
   mm_wave_sync();
-  const JvpNet net = jvp_net<T>(M);
+  JvpNet net = jvp_net<T>(M);
+  net.ptab = ptab ? 1 : 0;
   switch (M.acts[0]) {  // wave-uniform
     case KR_ACT_TANH: mlp_jvp_tile<T, KR_ACT_TANH, VAR>(net, scratch, lane); break;
     case KR_ACT_SOFTPLUS: mlp_jvp_tile<T, KR_ACT_SOFTPLUS, VAR>(net, scratch, lane); break;
@@ -479,7 +491,7 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
         if (k * n + e < 25) out[k * n + e] = v[e];
     }
     {  // (no branch on the role here either: a lane without a column adds its zero row)
-      const int row = col > 0 ? 16 * iv + col - 1 : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
+      const int row = col > 0 ? (xrow >= 0 ? xrow : 16 * iv + col - 1) : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
       const bool has = col > 0;  // (a select, not a product: the rows of a missing interval may hold NaN)
       const f32x4* dr = reinterpret_cast<const f32x4*>(dreg + (size_t)row * (MJ_DOUT_LD * 4));
 #pragma unroll
