@@ -521,7 +521,10 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
 #ifdef KR_MS_STAMPS
     unsigned long long ta = tq;
 #endif
-    bool chord = storing && have_fac && dn_prev > T(0) && dn_prev <= T(1e-2);
+    // (with the MLP on the factors in Es do not survive a sweep - the evaluator's scratch lies over them - so there is no
+    //  chord check; the chord branch is only entered right after a full update, for the p columns)
+    const bool small_prev = storing && have_fac && dn_prev > T(0) && dn_prev <= T(1e-2);
+    bool chord = !NN && small_prev;
     T d[6];
     T updY[MS_P - 1];
     T* dYb = XB;  // [g][19] scratch for dY_1 .. dY_{P-2} (p rows below)
@@ -550,7 +553,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     for (int g = 0; g < MS_P - 1; ++g) updY1[g] = T(0);
     bool quick = false;
     float quick_est = 0.f;
-    if (!NN && S.quick_ok && chord && amp > 0.f) {  // (with the MLP on the Jacobian is approximate and the ratio not audited)
+    if (!NN && S.quick_ok && small_prev && amp > 0.f) {  // (with the MLP on the ratio is not audited)
       {
         T er[19];
         state_to_rows(y, er);
