@@ -372,7 +372,9 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
   // time steps (it only corrects the Jacobian: a block one or two sweeps old is accurate to a few per cent, which puts
   // the contraction at ~1e-5), their network evaluations ride on the free columns 6..14 of sample tile 0, and the
   // Newton update gets one step of defect correction, d = d0 + Jt^-1 (B dp0), through the factors just computed.
-  constexpr bool PCOL = NN && PERSIST && SCHEME == KR_EULER;
+  // (fp64 only: with fp32's tolerance of 1e-5 the third sweep of a step is the accepted one either way, and the extra
+  //  lanes and the second solve only cost - measured 0.55 -> 0.56 ms per step at cfg3)
+  constexpr bool PCOL = NN && PERSIST && SCHEME == KR_EULER && sizeof(T) == 8;
   const bool pl = PCOL && idle;                     // lanes 58..63
   const int pslot = lane - (7 + 17 * (MS_P - 1));   // 0..5 on those lanes
   T* Bp = L.Bp;
@@ -386,7 +388,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       const int ga = rot == 0 ? 1 : rot == 1 ? 3 : 2, gb = rot == 0 ? 2 : rot == 1 ? 1 : 3;
       const int gu = 6 - ga - gb;  // the interval nobody serves this sweep
       S.prot += 1;
-      Cl.role.ptab = true;
+      Cl.role.ptab = 1;
       if (pl) {
         pg = pslot < 3 ? ga : gb;
         pc = pslot < 3 ? pslot : pslot - 3;

@@ -88,6 +88,7 @@ struct MswLds {
   T* red;    // [W][32] reduction scratch
   T* Es;     // [W] blocks of wblk elements: end states Es_w [64][19], then the local-map tiles Lt_w [2][19][MSW_LT_LD]
   size_t wblk;
+  T* Bp;     // MLP on: [W][3 intervals][3 directions][19] p-column blocks (+1), see msw_newton; then dP [P][3] (+pad)
   __device__ __forceinline__ T* es(int wave) const { return Es + (size_t)wave * wblk; }
   __device__ __forceinline__ T* lt(int wave) const { return Es + (size_t)wave * wblk + ((64 * 19 + 3) & ~3); }
 };
@@ -100,12 +101,13 @@ __host__ __device__ constexpr size_t msw_wave_block(bool nn) {
   return (n + 3) & ~size_t(3);
 }
 // hist_lds = false: the history records live in global memory (the persistent kernel with the MLP on)
+constexpr int MSW_BP_W = 3 * 3 * 19 + 1;  // p-column blocks of one wavefront
 template <typename T, int W>
 __host__ __device__ inline size_t msw_lds_elems(int N, bool nn = false, bool hist_lds = true) {
   constexpr int P = MswGeo<W>::P;
   auto r4 = [](size_t n) { return (n + 3) & ~size_t(3); };
   return (hist_lds ? r4((size_t)N * HS_LEAN) : 0) + r4(P * 19) + r4(CD_SIZE) + 48 + r4(W * 19 * 8) + r4(P * 19) + r4(P * 4) +
-         W * 32 + (size_t)W * msw_wave_block<T>(nn);
+         W * 32 + (size_t)W * msw_wave_block<T>(nn) + (nn ? (size_t)W * MSW_BP_W + r4(P * 3) : 0);
 }
 template <typename T, int W>
 __device__ __forceinline__ MswLds<T, W> msw_carve(T* smem, int N, bool nn = false, bool hist_lds = true) {
@@ -122,6 +124,7 @@ __device__ __forceinline__ MswLds<T, W> msw_carve(T* smem, int N, bool nn = fals
   L.red = L.sp + r4(P * 4);
   L.Es = L.red + W * 32;
   L.wblk = msw_wave_block<T>(nn);
+  L.Bp = nn ? L.Es + (size_t)W * L.wblk : nullptr;
   return L;
 }
 
@@ -449,7 +452,9 @@ struct MswUpd {
   int pg, pprow;
   bool plane, glane;
 };
-template <typename T, int W>
+// SECOND: a second solve through the same forward-difference columns (they are still in Es) with the base end states
+// replaced by what the caller passes in y - the defect correction for the p columns (msw_newton, MLP on).
+template <typename T, int W, bool SECOND = false>
 __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRole& R, int lane, const RodState<T>& y,
                                              T hstep, MswUpd<T>& U
 #ifdef KR_MS_STAMPS
@@ -477,7 +482,7 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
       }
       wave_sync();
       res_local = msw_residual_local<T, W>(Es, Xs, L.cold, R, lane);
-      if (col > 0) {
+      if (col > 0 && !SECOND) {
         const T ih = fast_rcp(hstep);
         T e0[19];
 #pragma unroll
@@ -809,21 +814,67 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
   const T kappa_in = S.kappa;
   bool below = false;
   float amp = -1.f;  // |update| / |residual| of the last full iteration of this solve (residual test, see ms_newton)
+  // p columns of the Jacobian (kr_ms_impl.hpp, ms_newton: the network reads the start position of an interval, the physics
+  // does not).  The first wavefront has six spare lanes for its three interior intervals (two per sweep, in rotation), the
+  // others thirteen for their three (all of them, every sweep).
+  // (fp64 only, as there: measured with fp32 the extra lanes and the second solve cost 8 - 13 % and save no sweep)
+  constexpr bool PCOL = NN && sizeof(T) == 8;
+  const int nact = wave == 0 ? 58 : 51;              // lanes with a forward-difference role
+  const int pslot = lane - nact;                     // >= 0 on the spare lanes
+  const bool pl_any = PCOL && idle && pslot < (wave == 0 ? 6 : 9);
+  T* Bw = PCOL ? L.Bp + (size_t)wave * MSW_BP_W : nullptr;   // [3][3][19]: local interval (0..2 after the first), direction, row
+  T* dPl = PCOL ? L.Bp + (size_t)W * MSW_BP_W : nullptr;     // [P][3]: p update of every interval start
 
   while (true) {
+    // ---- role of the spare lanes in this sweep --------------------------------------------------------
+    int iv_l = iv, s_l = R.s_i, len_l = R.len_i, pk = 0, pc = 0;   // pk: index of the p lane's interval in Bw
+    MswNn<T> nl = nn;
+    if constexpr (PCOL) {
+      nl.role.ptab = wave == 0 ? 1 : 2;
+      int gu = 0;
+      if (wave == 0) {
+        const int rot = S.prot % 3;  // local intervals served: (1, 2), (3, 1), (2, 3)
+        const int ga = rot == 0 ? 1 : rot == 1 ? 3 : 2, gb = rot == 0 ? 2 : rot == 1 ? 1 : 3;
+        gu = 6 - ga - gb;
+        if (pl_any) { const int gl = pslot < 3 ? ga : gb; pk = gl - 1; pc = pslot < 3 ? pslot : pslot - 3; iv_l = gl; }
+      } else if (pl_any) {
+        pk = pslot / 3; pc = pslot - 3 * pk; iv_l = R.g0 + pk;
+      }
+      S.prot += 1;
+      if (pl_any) {
+        s_l = msw_start(iv_l, N, P);
+        len_l = R.sbase + (iv_l < (N - 1) % P ? 1 : 0);
+        nl.role.iv = wave == 0 ? pk + 1 : pk; nl.role.col = 1; nl.role.idle = false;
+        nl.role.xrow = wave == 0 ? 6 + 3 * pk + pc : 48 + 3 * pk + pc;
+      } else if (wave == 0) {
+        if (col == 0 && !idle) nl.role.zrow = R.ivl < 3 ? 6 + 3 * (gu - 1) + R.ivl : 15;
+      } else {
+        // rows 57..63 of sample tile 3: the three unperturbed lanes and the four lanes without any role
+        if (col == 0 && !idle) nl.role.zrow = 57 + R.ivl;
+        else if (idle) nl.role.zrow = 60 + (pslot - 9);
+      }
+    }
     // ---- start state of this lane, forward-difference step of its column -------------------------------
     T yr[19];
 #pragma unroll
-    for (int q = 0; q < 19; ++q) yr[q] = Xs[iv * 19 + q];
+    for (int q = 0; q < 19; ++q) yr[q] = Xs[iv_l * 19 + q];
     const T hstep = col > 0 ? S.fd_eps * fmax(fabs(Xs[iv * 19 + (R.comp > 0 ? R.comp : 3)]), T(1)) : T(1);
 #pragma unroll
     for (int q = 3; q < 19; ++q) yr[q] += q == R.comp ? hstep : T(0);
+    T hp = T(1);
+    if constexpr (PCOL) {
+      if (pl_any) {
+        hp = S.fd_eps * fmax(fabs(Xs[iv_l * 19 + pc]), T(1));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) yr[q] += q == pc ? hp : T(0);
+      }
+    }
     RodState<T> y = rows_to_state(yr);
     const bool st = (storing || flush) && col == 0 && !idle;
 
     // ---- sweep over this lane's sub-interval (explicit Euler, cosserat_ode.py:198-201) ------------------
     T hv[HS_LEAN];
-    load_hist_vec<T, HS_LEAN>(hist + (size_t)R.s_i * HS_LEAN, hv);
+    load_hist_vec<T, HS_LEAN>(hist + (size_t)s_l * HS_LEAN, hv);
     auto point = [&](auto store_tag, int j, bool live) __attribute__((always_inline)) {
       constexpr bool STORE = decltype(store_tag)::value;
       RodState<T> k1;
@@ -834,7 +885,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 #else
       if constexpr (false)
 #endif
-        nn_correct<T, HS_LEAN, EV, true>(*nn.M, nullptr, nullptr, 0, nn.tile, lane, nn.role, y, hv, nn.tf, k1, v, u);
+        nn_correct<T, HS_LEAN, EV, true>(*nl.M, nullptr, nullptr, 0, nl.tile, lane, nl.role, y, hv, nl.tf, k1, v, u);
       if constexpr (STORE) {
         if (st && live) {
           T rec[KR_SLOTS];
@@ -857,8 +908,8 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       // (shorter) interval keep running on the last grid point and do not commit (kr_ms_impl.hpp, ms_newton)
       const int lmax = R.sbase + (R.g0 < (N - 1) % P ? 1 : 0);  // (the long intervals come first)
       for (int t = 0; t < lmax; ++t) {
-        const bool live = t < R.len_i;
-        const int j = live ? R.s_i + t : R.s_i + R.len_i - 1;
+        const bool live = t < len_l;
+        const int j = live ? s_l + t : s_l + len_l - 1;
         const RodState<T> y_in = y;
         if (storing || flush) point(std::true_type{}, j, live);  // (wave-uniform choice)
         else point(std::false_type{}, j, true);
@@ -925,6 +976,65 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
 #else
     msw_condense<T, W>(L, R, lane, y, hstep, U);
 #endif
+    if constexpr (PCOL) {
+      // ---- p columns: blocks from the spare lanes, then one step of defect correction (kr_ms_impl.hpp) ----------
+      {
+        T er[19];
+        state_to_rows(y, er);
+        if (pl_any) {  // column pc of B = dE/dp - [I; 0] of local interval (wave 0: pk + 1, others: pk)
+          const T ihp = fast_rcp(hp);
+          const int l0p = msw_l0(wave, wave == 0 ? pk + 1 : pk);
+          T e0[19];
+#pragma unroll
+          for (int q = 0; q < 19; ++q) e0[q] = Es[l0p * 19 + q];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 19; ++q) Bw[(pk * 3 + pc) * 19 + q] = (er[q] - e0[q]) * ihp - (q == pc ? T(1) : T(0));
+        }
+      }
+      if (U.plane) dPl[U.pg * 3 + U.pprow] = U.updP;
+      __syncthreads();
+      if (U.dnf <= 3.0e38f) {   // (uniform over the workgroup)
+        // "end states" of the second solve: Y_{g+1} + B_g dY_g[p] (tip rows of the last interval: F_tip + ...)
+        RodState<T> ysub = y;
+        if (col == 0 && !idle) {
+          const int g = iv;
+          const int kb = wave == 0 ? R.ivl - 1 : R.ivl;   // index of this interval's block (interval 0 has none)
+          T rows[19];
+#pragma unroll
+          for (int q = 0; q < 19; ++q) {
+            T cp = T(0);
+            if (g > 0) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) cp = fma(Bw[(kb * 3 + c) * 19 + q], dPl[g * 3 + c], cp);
+            }
+            T basev;
+            if (g < P - 1) basev = Xs[(g + 1) * 19 + q];
+            else basev = (q >= 7 && q < 13) ? L.cold[CD_FTIP + (q - 7)] : T(0);
+            rows[q] = basev + cp;
+          }
+          ysub = rows_to_state(rows);
+        }
+        MswUpd<T> U2;
+#ifdef KR_MS_STAMPS
+        msw_condense<T, W, true>(L, R, lane, ysub, hstep, U2, stamps, ta);
+#else
+        msw_condense<T, W, true>(L, R, lane, ysub, hstep, U2);
+#endif
+        U.updP += U2.updP; U.updG += U2.updG;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) U.updR[k] += U2.updR[k];
+        float nf = 0.f;
+        if (U.plane) nf = update_ratio(U.updP, U.xsP);
+        if (U.glane) nf = fmaxf(nf, update_ratio(U.updG, U.xsG));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int g = wave == 0 ? 1 + k : R.g0 + k;
+          if (k < 3 && g < P && (lane >> 4) == k) nf = fmaxf(nf, update_ratio(U.updR[k], U.xsR[k]));
+        }
+        U.dnf = msw_max<W>(nf, redf, wave, lane);
+      }
+    }
     float dnf = U.dnf;
     res_local = U.res_local;
     const bool finite = dnf <= 3.0e38f;
@@ -1307,6 +1417,9 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   const MswRole R = msw_role<W>(wave, lane, N);
   MsStamps stamps;
   if (wave == 0) ms_cold_fill<T>(Pc, L.cold, lane);
+  if constexpr (NN) {  // p-column blocks of the Jacobian (msw_newton): none known yet
+    for (int e = threadIdx.x; e < W * MSW_BP_W + ((P * 3 + 3) & ~3); e += WAVE * W) L.Bp[e] = T(0);
+  }
   const T* s0 = A.states + rod * rod_elems;
   const T* sp = A.prev_init ? A.prev_init + rod * rod_elems : s0;
   if constexpr (!GL) {

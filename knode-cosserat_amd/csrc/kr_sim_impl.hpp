@@ -239,7 +239,7 @@ struct NnRole {
   bool idle = false, jvp = false;
   int zrow = -1;  // dx row a lane without a column zeroes (-1: the layout of the one-wavefront kernels)
   int xrow = -1;  // dx row of a lane with a column, when it is not 16 iv + col - 1 (p columns)
-  bool ptab = false;  // wavefront-uniform: columns 6..14 of sample tile 0 carry p columns (mlp_jvp.hpp, jvp_scale_pack)
+  int ptab = 0;   // wavefront-uniform: where the p columns' samples sit (mlp_jvp.hpp, jvp_scale_pack; 0: there are none)
 };
 // JVP_ONLY: the caller guarantees M.mfma_ok && M.jvp_ok and a lane role (kr_msw_impl.hpp with the MLP on) - no other
 // evaluator is compiled in, so that the register limit of a two-wavefronts-per-SIMD kernel holds for all its callees

@@ -204,11 +204,15 @@ __device__ __forceinline__ void jvp_scale_pack(const f32x4 (&dh)[4][4], const MJ
                                                int ptab) {
   const int q = lane >> 4;
   const int c0 = lane & 15;
-  const int tbl0 = (ptab && c0 >= 6 && c0 < 15) ? 1 + (c0 - 6) / 3 : 0;
+  // ptab 1: the one-wavefront layout and the first wavefront of a rod (tile 0: interval 0 with 6 columns, then p columns of
+  // the intervals 1..3 in columns 6..14); ptab 2: the other wavefronts of a rod (three intervals with 16 columns each in the
+  // tiles 0..2, their p columns in the columns 0..8 of tile 3)
+  const int tbl0 = (ptab == 1 && c0 >= 6 && c0 < 15) ? 1 + (c0 - 6) / 3 : 0;
+  const int tbl3 = (ptab == 2 && c0 < 9) ? c0 / 3 : 3;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     f32x4 g[4];
-    const int tbl = s == 0 ? tbl0 : s;
+    const int tbl = s == 0 ? tbl0 : s == 3 ? tbl3 : s;
 #pragma unroll
     for (int o = 0; o < 4; ++o) g[o] = *reinterpret_cast<const MJ_LDS f32x4*>(actp + tbl * 64 + 16 * o + 4 * q);
 #pragma unroll
@@ -422,7 +426,7 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
 // x in, NN(x) (base lanes) or NN(x_base) + J dx (the others) out.
 template <typename T, int VAR = 0>
 __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
-                                             bool idle, int zrow, T (&out)[25], int xrow = -1, bool ptab = false) {
+                                             bool idle, int zrow, T (&out)[25], int xrow = -1, int ptab = 0) {
   using V = typename MjVec<T>::type;
   constexpr int n = MjVec<T>::n;
   T* xb = scratch;
@@ -472,7 +476,7 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
   }
   mm_wave_sync();
   JvpNet net = jvp_net<T>(M);
-  net.ptab = ptab ? 1 : 0;
+  net.ptab = ptab;
   switch (M.acts[0]) {  // wave-uniform
     case KR_ACT_TANH: mlp_jvp_tile<T, KR_ACT_TANH, VAR>(net, scratch, lane); break;
     case KR_ACT_SOFTPLUS: mlp_jvp_tile<T, KR_ACT_SOFTPLUS, VAR>(net, scratch, lane); break;
