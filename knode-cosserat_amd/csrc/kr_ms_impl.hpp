@@ -1150,9 +1150,12 @@ constexpr int MS_EPL = (MS_NE + WAVE - 1) / WAVE;
 // NC: taps of the fitted recurrence.  3 with the MLP off (a constant plus one oscillation: what a rod driven by smooth
 // tensions does, predicted to ~5e-6); 5 with the MLP on - the network makes the response nonlinear, its harmonics need two
 // more taps (first guess 5e-3 -> 8e-4 on the fast rods of cfg3, 8e-4 -> 4e-5 on slow ones; measured with the oracle).
+#ifndef KR_NN_TAPS
+#define KR_NN_TAPS 5
+#endif
 template <typename T, int NC = 3>
 struct MsPred {
-  static_assert(NC == 3 || NC == 5, "three or five taps");
+  static_assert(NC == 3 || NC == 5 || NC == 7, "three, five or seven taps");
   static constexpr int nc = NC;
   T Hx[MS_EPL][MS_HLEV];  // Hx[q][k]: element lane + 64 q, k steps back
   // adaptive linear predictor: x(t+1) ~ a0 x(t) + a1 (x(t) - x(t-1)) + a2 (x(t) - 2 x(t-1) + x(t-2)) [+ a3, a4 times the
@@ -1170,16 +1173,22 @@ template <typename T, int NC>
 __device__ __forceinline__ void lp_basis(const T (&H)[MS_HLEV], double (&b)[NC]) {
   const double h0 = (double)H[0], h1 = (double)H[1], h2 = (double)H[2];
   b[0] = h0; b[1] = h0 - h1; b[2] = h0 - 2.0 * h1 + h2;
-  if constexpr (NC == 5) {
+  if constexpr (NC >= 5) {
     const double h3 = (double)H[3], h4 = (double)H[4];
     b[3] = h0 - 3.0 * h1 + 3.0 * h2 - h3;
     b[4] = h0 - 4.0 * h1 + 6.0 * h2 - 4.0 * h3 + h4;
+    if constexpr (NC == 7) {
+      const double h5 = (double)H[5], h6 = (double)H[6];
+      b[5] = h0 - 5.0 * h1 + 10.0 * h2 - 10.0 * h3 + 5.0 * h4 - h5;
+      b[6] = h0 - 6.0 * h1 + 15.0 * h2 - 20.0 * h3 + 15.0 * h4 - 6.0 * h5 + h6;
+    }
   }
 }
 template <int NC>
 __device__ __forceinline__ double lp_eval(const double (&a)[NC], const double (&b)[NC]) {
   double s = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];  // (the order of the three-tap version)
-  if constexpr (NC == 5) s += a[3] * b[3] + a[4] * b[4];
+  if constexpr (NC >= 5) s += a[3] * b[3] + a[4] * b[4];
+  if constexpr (NC == 7) s += a[5] * b[5] + a[6] * b[6];
   return s;
 }
 // normal equations of the weighted fit: upper triangle row by row, then the right-hand side
@@ -1276,7 +1285,8 @@ __device__ __forceinline__ void ms_pred_save(const MsPred<T, NC>& Q, double* img
   u[6 * WAVE + lane] = (Q.lp_have ? 1.0 : 0.0) + 2.0 * (double)Q.lp_age;
   // (row 7: lp_good, and in lanes 1, 2 the fourth and fifth tap - everything here is uniform over the wavefront)
   double r7 = Q.lp_good ? 1.0 : 0.0;
-  if constexpr (NC == 5) r7 = lane == 1 ? Q.lpa[3] : lane == 2 ? Q.lpa[4] : r7;
+  if constexpr (NC >= 5) r7 = lane == 1 ? Q.lpa[3] : lane == 2 ? Q.lpa[4] : r7;
+  if constexpr (NC == 7) r7 = lane == 3 ? Q.lpa[5] : lane == 4 ? Q.lpa[6] : r7;
   u[7 * WAVE + lane] = r7;
 }
 template <typename T, int NC>
@@ -1295,7 +1305,8 @@ __device__ __forceinline__ void ms_pred_load(MsPred<T, NC>& Q, const double* img
   Q.lp_have = (hv & 1) != 0;
   Q.lp_age = hv >> 1;
   Q.lp_good = __builtin_amdgcn_readfirstlane((int)u[7 * WAVE + 0]) != 0;
-  if constexpr (NC == 5) { Q.lpa[3] = u[7 * WAVE + 1]; Q.lpa[4] = u[7 * WAVE + 2]; }
+  if constexpr (NC >= 5) { Q.lpa[3] = u[7 * WAVE + 1]; Q.lpa[4] = u[7 * WAVE + 2]; }
+  if constexpr (NC == 7) { Q.lpa[5] = u[7 * WAVE + 3]; Q.lpa[6] = u[7 * WAVE + 4]; }
 }
 
 // writes the start values of the coming step into Xs (boundary rows of interval 0 from the cold table)
@@ -1484,7 +1495,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
     // kr_simulate_batch, one launch per step: the predictor of the persistent kernel, carried from launch to
     // launch through its image in HBM
     double* img = A.pred + (size_t)rod * MS_PRED_ROWS * WAVE;
-    MsPred<T, NN ? 5 : 3> Q;
+    MsPred<T, NN ? KR_NN_TAPS : 3> Q;
     if (A.pred_reset) ms_pred_init<T>(Q, lane, R, A.cur + rod * rod_elems, A.prev + rod * rod_elems, A.pred_has_prev != 0, A.pred_limit);
     else ms_pred_load<T>(Q, img, lane);
     S.kappa = Q.kappa;
@@ -1588,7 +1599,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
       for (int c = 0; c < 12; ++c) regP[q][c] = T(0);
     }
   }
-  MsPred<T, NN ? 5 : 3> Q;
+  MsPred<T, NN ? KR_NN_TAPS : 3> Q;
   double* img = A.pred_io ? A.pred_io + (size_t)rod * MS_PRED_ROWS * WAVE : nullptr;
   if (img && A.pred_load && !resumed) ms_pred_load<T>(Q, img, lane);
   else ms_pred_init<T>(Q, lane, R, s0, sp, resumed || A.prev_init != nullptr, A.predictor);

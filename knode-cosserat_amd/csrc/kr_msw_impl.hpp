@@ -383,21 +383,30 @@ __device__ __forceinline__ void mswp_update(MsPred<T, NC>& Q, int order, int sta
         lp_accumulate<NC>(Sn, b, x, w);
       }
     }
-    if constexpr (lp_nsum<NC>() <= 16) {
-      msw_sum_n<W, lp_nsum<NC>()>(Sn, redd, wave, lane);
-    } else {  // (the reduction scratch holds 16 doubles per wavefront: matrix and right-hand side one after the other)
-      constexpr int NM = NC * (NC + 1) / 2;
-      double Sa[NM], Sb[NC];
+    {  // (the reduction scratch holds 16 doubles per wavefront: in chunks)
+      constexpr int NS = lp_nsum<NC>();
+      constexpr int C0 = NS < 16 ? NS : 16, C1 = NS - C0 < 16 ? (NS - C0 > 0 ? NS - C0 : 1) : 16, C2 = NS - C0 - C1 > 0 ? NS - C0 - C1 : 1;
+      static_assert(NS <= 48, "three chunks");
+      double S0[C0], S1[C1], S2[C2];
 #pragma unroll
-      for (int k = 0; k < NM; ++k) Sa[k] = Sn[k];
+      for (int k = 0; k < C0; ++k) S0[k] = Sn[k];
+      msw_sum_n<W, C0>(S0, redd, wave, lane);
 #pragma unroll
-      for (int k = 0; k < NC; ++k) Sb[k] = Sn[NM + k];
-      msw_sum_n<W, NM>(Sa, redd, wave, lane);
-      msw_sum_n<W, NC>(Sb, redd, wave, lane);
+      for (int k = 0; k < C0; ++k) Sn[k] = S0[k];
+      if constexpr (NS > 16) {
 #pragma unroll
-      for (int k = 0; k < NM; ++k) Sn[k] = Sa[k];
+        for (int k = 0; k < C1; ++k) S1[k] = Sn[C0 + k];
+        msw_sum_n<W, C1>(S1, redd, wave, lane);
 #pragma unroll
-      for (int k = 0; k < NC; ++k) Sn[NM + k] = Sb[k];
+        for (int k = 0; k < C1; ++k) Sn[C0 + k] = S1[k];
+      }
+      if constexpr (NS > 32) {
+#pragma unroll
+        for (int k = 0; k < C2; ++k) S2[k] = Sn[C0 + C1 + k];
+        msw_sum_n<W, C2>(S2, redd, wave, lane);
+#pragma unroll
+        for (int k = 0; k < C2; ++k) Sn[C0 + C1 + k] = S2[k];
+      }
     }
     double a[NC];
     if (lp_solve<NC>(Sn, a)) {
@@ -1433,7 +1442,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   }
   const int ne = R.K * 19;
   T* Xl = L.Xs + R.g0 * 19;
-  MsPred<T, NN ? 5 : 3> Q;
+  MsPred<T, NN ? KR_NN_TAPS : 3> Q;
   double* img = A.pred_io ? A.pred_io + ((size_t)rod * W + wave) * MS_PRED_ROWS * WAVE : nullptr;
   if (img && A.pred_load) ms_pred_load<T>(Q, img, lane);
   else mswp_init<T>(Q, lane, ne, R.g0, N, P, s0, sp, A.prev_init != nullptr, A.predictor);
