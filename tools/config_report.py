@@ -128,6 +128,19 @@ for dt in (torch.float64, torch.float32):
     h.simulate(ctl, st, Gs, ring=True, use_nn=True, status=status)
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) / TS
     print(f"      forward sim, MLP inside every sweep, {str(dt):14s}: {el*1e3:6.3f} ms/step -> {1024/el/1e3:7.1f} k rod-steps/s (unconverged {int((status!=0).sum())})")
+for Bs in (512, 256):  # smaller batches: several wavefronts per rod (kr_mswn_impl.hpp)
+    for dt in (torch.float64, torch.float32):
+        TS = 60
+        ctl = torch.as_tensor(orc.batch_sine_controls(Bs, TS, rr.del_t, 1235), device=dev).to(dt).contiguous()
+        st = h.new_state(Bs, dt, n_slots=3); h.init_straight(st[0]); Gs = torch.zeros((Bs, 6), dtype=dt, device=dev)
+        status = torch.zeros((Bs, TS), dtype=torch.int32, device=dev)
+        h.simulate(ctl, st, Gs, ring=True, use_nn=True, status=status)   # (first call of this instantiation)
+        st = h.new_state(Bs, dt, n_slots=3); h.init_straight(st[0]); Gs.zero_()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        h.simulate(ctl, st, Gs, ring=True, use_nn=True, status=status)
+        torch.cuda.synchronize(); el = (time.perf_counter() - t0) / TS
+        print(f"      ... the same at B={Bs:4d}, {str(dt):14s}: {el*1e3:6.3f} ms/step -> {Bs/el/1e3:7.1f} k rod-steps/s "
+              f"({h.get_option('last_waves_per_rod')} wavefronts per rod, unconverged {int((status!=0).sum())})")
 
 print("cfg4  training loop shard: 512 trajectories per GPU (4096 over 8), train_len 30, 28->512->25")
 for N, kp in ((10, [3, 5, 7, 9]), (100, [33, 55, 77, 99])):
