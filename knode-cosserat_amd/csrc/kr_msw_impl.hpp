@@ -889,11 +889,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       RodState<T> k1;
       V3<T> v, u;
       ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fconst, k1, v, u);
-#ifndef KR_MSWN_NO_EVAL
       if constexpr (NN)  // every wavefront evaluates the network for its own lanes (cosserat_ode.py:169-184)
-#else
-      if constexpr (false)
-#endif
         nn_correct<T, HS_LEAN, EV, true>(*nl.M, nullptr, nullptr, 0, nl.tile, lane, nl.role, y, hv, nl.tf, k1, v, u);
       if constexpr (STORE) {
         if (st && live) {
