@@ -124,6 +124,10 @@ int kr_destroy(kr_handle* h);
  *                    every batch size measured; lower it to send large batches to the single-shooting kernel)
  *   "persistent"     1 (default) / 0: kr_simulate_batch runs all steps in one launch when the
  *                    multiple-shooting kernel applies
+ *   "waves_per_rod"  0 auto (default) / 1 / 2 / 4: wavefronts that share one rod (7 or 13 sub-intervals instead of 4) -
+ *                    for batches that would leave SIMDs idle (B waves_per_rod <= 1024).  With the MLP on: the persistent
+ *                    form of kr_simulate_batch only (Euler sweeps, a network the matrix-core evaluator serves).
+ *                    "last_waves_per_rod" / "last_sim_path" (read-only) tell what the last call ran.
  *   "mlp_grad_accumulate" 0 (default) / 1: see kr_adam_step
  *   "keep_predictor" 0 (default) / 1: kr_simulate_batch leaves the state of its start-value predictor behind
  *                    and the next call with the same batch size resumes from it - for a simulation that is
