@@ -671,12 +671,94 @@ def gen_round3():
     save("round3", **out)
 
 
+BC_PARAMS = dict(
+    F_tip=np.array([0.05, -0.02, 0.1]), M_tip=np.array([1e-3, 2e-3, -1e-3]),
+    p0=np.array([0.01, -0.02, 0.03]),
+    h0=1.1 * np.array([0.96, 0.10, -0.15, 0.05]),          # tilted AND not of unit length
+    q0=np.array([0.01, -0.005, 0.002]), w0=np.array([0.02, -0.01, 0.03]),   # base moving at a constant twist
+    tendon_dirs=np.array([[0.70, 0.68, 0.20], [-0.66, 0.75, -0.10], [-0.72, -0.69, 0.15], [0.60, -0.80, -0.25]]),
+)
+
+
+def bc_robot(N, mod=None):
+    """A rod with EVERY boundary / load parameter away from its default (cosserat_ode.py:28-29 F_tip, M_tip; :37-41
+    tendon_dirs; :44-47 p0, h0, q0, w0 - they enter :194-195 and :206-207)."""
+    r = np_robot(mod, N)
+    for k, v in BC_PARAMS.items():
+        setattr(r, k, v.copy())
+    return r
+
+
+def gen_bc():
+    """Round 4: the reference's full parameter surface.  simulate at N = 20 / 100 with a tip wrench, a tilted non-unit
+    base quaternion, p0 != 0, a moving base and asymmetric tendon directions with a z component; the Euler and RK4
+    residual rows of the same rod; the same with the residual MLP on."""
+    rng = np.random.default_rng(44)
+    out = {f"par_{k}": v for k, v in BC_PARAMS.items()}
+    for N, T in ((20, 30), (100, 30)):
+        r = bc_robot(N)
+        ctl = ref_ctl.calc_controls("sine", 1.0, r.del_t, T)
+        traj, ier, nfev = run_sim(r, ctl)
+        print(f"  bc N={N}: ier all 1 = {bool(np.all(ier == 1))}, mean nfev {nfev.mean():.1f}")
+        tag = f"sim_N{N}"
+        out[f"{tag}_ctl"], out[f"{tag}_ier"] = np.array(ctl), ier
+        out[f"{tag}_tip"], out[f"{tag}_last"] = traj[:, :3, -1], traj[-1]
+        if N == 20:
+            out[f"{tag}_traj"] = traj[:, :25]
+        else:
+            out[f"{tag}_every10"] = traj[::10, :25]
+    # a step input on top (the acceptance / fallback ladders of the persistent kernels see a jump)
+    r = bc_robot(40)
+    ctl = ref_ctl.calc_controls("step", 1.0, r.del_t, 36)
+    traj, ier, _ = run_sim(r, ctl)
+    print(f"  bc step N=40: ier all 1 = {bool(np.all(ier == 1))}")
+    out["step_N40_ctl"], out["step_N40_ier"], out["step_N40_traj"] = np.array(ctl), ier, traj[:, :25]
+    # residual rows
+    for N in (20, 100):
+        r = bc_robot(N)
+        y, z, yp, zp, G0, tens = converged_state(
+            r, 6, lambda T: ref_ctl.calc_controls("sine", 1.0, r.del_t, T))
+        yh = r.c1 * y + r.c2 * yp
+        zh = r.c1 * z + r.c2 * zp
+        yh_int = 0.5 * (yh[:, :-1] + yh[:, 1:])
+        zh_int = 0.5 * (zh[:, :-1] + zh[:, 1:])
+        r.tendon_tensions = tens
+        tag = f"res_N{N}"
+        out[f"{tag}_y"], out[f"{tag}_z"], out[f"{tag}_yp"], out[f"{tag}_zp"] = y, z, yp, zp
+        out[f"{tag}_tens"] = tens
+        Gs = G0[None, :] * (1 + 0.05 * rng.standard_normal((3, 6))) + 1e-3 * rng.standard_normal((3, 6))
+        out[f"{tag}_G"] = Gs
+        for scheme, fn in (("euler", r.getResidualEuler), ("rk4", r.getResidualRK4)):
+            rs, ys, zs = [], [], []
+            for G in Gs:
+                yy, zz = y.copy(), z.copy()
+                with np.errstate(all="ignore"):
+                    rs.append(fn(G, yy, zz, yh, yh_int, zh, zh_int))
+                ys.append(yy)
+                zs.append(zz)
+            out[f"{tag}_{scheme}_r"] = np.array(rs)
+            out[f"{tag}_{scheme}_y"] = np.array(ys)
+            out[f"{tag}_{scheme}_z"] = np.array(zs)
+    # MLP on: the two-hidden-layer network of BASELINE cfg3 and the single-hidden-layer one of the reference's default shape
+    for name, sizes, N, T in (("elu6464", [28, 64, 64, 25], 24, 20), ("elu64", [28, 64, 25], 20, 20)):
+        mlp = orc.make_mlp(sizes, "elu", seed=5)
+        r = bc_robot(N)
+        inject_nn(r, mlp)
+        ctl = ref_ctl.calc_controls("sine", 1.5, r.del_t, T)
+        traj, ier, _ = run_sim(r, ctl)
+        print(f"  bc nn {name} N={N}: ier all 1 = {bool(np.all(ier == 1))}")
+        out[f"nn_{name}_ctl"], out[f"nn_{name}_ier"], out[f"nn_{name}_traj"] = np.array(ctl), ier, traj[:, :25]
+        out[f"nn_{name}_N"] = np.array(N)
+        out.update(mlp_arrays(f"mlp_{name}", mlp))
+    save("bc", **out)
+
+
 ALL = {
     "ode_kat": gen_ode_kat, "ode_torch_kat": gen_ode_torch_kat, "residual_kat": gen_residual_kat,
     "sim_cfg1": gen_sim_cfg1, "sim_n100": gen_sim_n100, "sim_n400": gen_sim_n400, "sim_misc": gen_sim_misc,
     "sim_nn": gen_sim_nn, "sim_more": gen_sim_more, "train_step": gen_train_step, "small": gen_small,
     "checkpoint": gen_checkpoint, "estimate_state": gen_estimate_state, "tres_grad": gen_tres_grad,
-    "round3": gen_round3,
+    "round3": gen_round3, "bc": gen_bc,
 }
 
 if __name__ == "__main__":

@@ -107,6 +107,30 @@ def test_cfg4_shard_training_step(torch_cuda, N):
     rob.compute_intermediate_terms()
     tr = KnodeTrainer(rob, traj, controls, kp)
     assert tr.Q == 59392 and tr.K == 4 and tr.steps == 29
+    # rows the HIP physics kernel produced (kr_next_segment_physics, kr_gather_targets) against the oracle, with
+    # calc_controls inputs: x = [y, z, tf] at column key-1 of the teacher-forced next state, base = y + ds * physics
+    # (z: physics), target = the true y at column key and z at key-1 (physics_train.py:345-352).  Sine and random trajectories,
+    # first / interior / last window step, every key point.
+    import cosserat_oracle as orc
+    D = orc.setup_params("damping", N).derived()
+    xs, bases, tgts = tr.x.cpu().numpy(), tr.base.cpu().numpy(), tr.target_rows[: tr.Q].cpu().numpy()
+    tj = traj.cpu().numpy().astype(np.float64)
+    for q in (0, 1, 2, 3, 4 * 29 + 5, 30001, 30002, 44444, 59391):
+        s_, k_ = divmod(q, 4)
+        m_, t_ = divmod(s_, T - 1)
+        col = kp[k_] - 1
+        Gn = tj[m_, t_ + 1]
+        y_, z_ = tj[m_, t_, :19], tj[m_, t_, 19:]
+        yp_, zp_ = (y_, z_) if t_ == 0 else (tj[m_, t_ - 1, :19], tj[m_, t_ - 1, 19:])
+        yh_, zh_ = D.c1 * y_ + D.c2 * yp_, D.c1 * z_ + D.c2 * zp_
+        tf_ = orc.tendon_force(D, ctl[m_, t_].astype(np.float32).astype(np.float64))
+        ys_, zz_ = orc.ode(D, Gn[:19, col], yh_[:, col], zh_[:, col], tf_)
+        want_x = np.concatenate([Gn[:19, col], zz_, tf_])
+        want_b = np.concatenate([Gn[:19, col] + D.ds * ys_, zz_])
+        assert np.allclose(xs[q, :28], want_x, rtol=2e-4, atol=2e-5 * np.abs(want_x).max()), q
+        assert np.allclose(bases[q], want_b, rtol=2e-4, atol=2e-5 * np.abs(want_b).max()), q
+        want_t = np.concatenate([Gn[:19, col + 1], Gn[19:25, col]])   # y rows at the key column, z rows one before (:352)
+        assert np.allclose(tgts[q], want_t, rtol=1e-6, atol=1e-7 * np.abs(want_t).max()), q
     w0 = [p.detach().clone() for p in rob.nn_models.parameters()]
     loss = tr.loss_and_grads()
     torch.cuda.synchronize()

@@ -304,3 +304,83 @@ def test_cfg2_rods_of_the_256_draw():
     with np.errstate(all="ignore"):
         traj = orc.simulate(D, ctl[0][:T], solver="fsolve")
     assert rel_l2(traj[:, :3, -1], g["cfg2_tip"][0][:T]) < 1e-9
+
+
+# ---------------------------------------------------------------------------
+# round 4: the reference's full parameter surface (fixture bc.npz: tip wrench, tilted non-unit h0, p0, moving base,
+# asymmetric tendon directions with a z component - cosserat_ode.py:28-29,37-41,44-47 entering :194-195,206-207)
+# ---------------------------------------------------------------------------
+def bc_params(g, N, mod=None):
+    P = orc.params_for(mod, N)
+    for k in ("F_tip", "M_tip", "p0", "h0", "q0", "w0", "tendon_dirs"):
+        setattr(P, k, np.array(g[f"par_{k}"], dtype=np.float64))
+    return P
+
+
+def test_bc_fixture_is_off_default():
+    g = load_golden("bc")
+    P0 = orc.RodParams()
+    for k in ("F_tip", "M_tip", "p0", "h0", "q0", "w0", "tendon_dirs"):
+        assert not np.allclose(g[f"par_{k}"], getattr(P0, k)), k
+    assert abs(np.linalg.norm(g["par_h0"]) - 1.0) > 0.05
+    assert np.all(np.abs(g["par_tendon_dirs"][:, 2]) > 0.05)
+
+
+@pytest.mark.parametrize("N", [20, 100])
+def test_bc_simulate(N):
+    g = load_golden("bc")
+    assert np.all(g[f"sim_N{N}_ier"] == 1)
+    D = bc_params(g, N).derived()
+    traj = orc.simulate(D, g[f"sim_N{N}_ctl"])
+    assert rel_l2(traj[:, :3, -1], g[f"sim_N{N}_tip"]) < 1e-10
+    assert rel_l2(traj[-1], g[f"sim_N{N}_last"]) < 1e-9
+    if N == 20:
+        assert rel_l2(traj[:, :25], g["sim_N20_traj"]) < 1e-9
+        trn = orc.simulate(D, g["sim_N20_ctl"], solver="newton")
+        assert rel_l2(trn[:, :25], g["sim_N20_traj"]) < 1e-7
+        # the boundary column is what the parameters say (cosserat_ode.py:194)
+        assert np.allclose(traj[5, 0:3, 0], g["par_p0"]) and np.allclose(traj[5, 3:7, 0], g["par_h0"])
+        assert np.allclose(traj[5, 13:16, 0], g["par_q0"]) and np.allclose(traj[5, 16:19, 0], g["par_w0"])
+    else:
+        assert rel_l2(traj[::10, :25], g["sim_N100_every10"]) < 1e-9
+
+
+def test_bc_step_input():
+    g = load_golden("bc")
+    assert np.all(g["step_N40_ier"] == 1)
+    traj = orc.simulate(bc_params(g, 40).derived(), g["step_N40_ctl"])
+    assert rel_l2(traj[:, :25], g["step_N40_traj"]) < 1e-9
+
+
+@pytest.mark.parametrize("N", [20, 100])
+@pytest.mark.parametrize("scheme", ["euler", "rk4"])
+def test_bc_residuals(N, scheme):
+    g = load_golden("bc")
+    D = bc_params(g, N).derived()
+    tag = f"res_N{N}"
+    y0, z0, yp, zp = g[f"{tag}_y"], g[f"{tag}_z"], g[f"{tag}_yp"], g[f"{tag}_zp"]
+    yh = D.c1 * y0 + D.c2 * yp
+    zh = D.c1 * z0 + D.c2 * zp
+    for k, G in enumerate(g[f"{tag}_G"]):
+        ref_r, ref_y, ref_z = g[f"{tag}_{scheme}_r"][k], g[f"{tag}_{scheme}_y"][k], g[f"{tag}_{scheme}_z"][k]
+        if not np.all(np.isfinite(ref_r)):
+            continue
+        y, z = y0.copy(), z0.copy()
+        with np.errstate(all="ignore"):
+            if scheme == "euler":
+                r = orc.residual_euler(D, G, y, z, yh, zh, g[f"{tag}_tens"])
+            else:
+                r = orc.residual_rk4(D, G, y, z, yh, 0.5 * (yh[:, :-1] + yh[:, 1:]), zh,
+                                     0.5 * (zh[:, :-1] + zh[:, 1:]), g[f"{tag}_tens"])
+        assert rel_l2(y, ref_y) < 1e-11 and rel_l2(z, ref_z) < 1e-11
+        assert np.allclose(r, ref_r, rtol=1e-9, atol=1e-11 * np.abs(ref_y[7:13]).max())
+
+
+@pytest.mark.parametrize("name", ["elu6464", "elu64"])
+def test_bc_simulate_with_mlp(name):
+    g = load_golden("bc")
+    assert np.all(g[f"nn_{name}_ier"] == 1)
+    mlp = orc.mlp_from_arrays(g, f"mlp_{name}")
+    D = bc_params(g, int(g[f"nn_{name}_N"])).derived()
+    traj = orc.simulate(D, g[f"nn_{name}_ctl"], mlp=mlp)
+    assert rel_l2(traj[:, :25], g[f"nn_{name}_traj"]) < 1e-9
