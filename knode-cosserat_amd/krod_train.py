@@ -55,9 +55,15 @@ class FlatBucket:
         self.loss = self.flat[off:off + 1]
 
     def all_reduce(self, group=None):
+        """group=None: the default process group; group=False: never reduce (a single-rank run inside a
+        multi-rank job)."""
         import torch.distributed as dist
+        if group is False:
+            return False
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            return True
+        return False
 
 
 class DevicePlateau:
@@ -114,6 +120,8 @@ class KnodeTrainer:
         # epilogue of the forward kernel and predictions() evaluates them on demand
         self.keep_pred = keep_pred
         self.group = group
+        self.time_allreduce = False
+        self.allreduce_events = []
         self.clamp_weights = clamp_weights
         h = robot._native()
         self.h = h
@@ -231,7 +239,14 @@ class KnodeTrainer:
                                                kn._ptr(self.dout), kn._ptr(self.ws), s))
         kn.check(h.lib.kr_mlp_backward(h._h, Q, self.n, self.dims_c, self.acts_c, Wp, kn._ptr(self.x), self.in_pad,
                                        kn._ptr(self.dout), kn._ptr(self.ws), dWp, dbp, s))
-        self.bucket.all_reduce(self.group)
+        if self.time_allreduce:  # (bench.py's data-parallel leg: HIP events around the collective, on the compute stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if self.bucket.all_reduce(self.group):
+                e1.record()
+                self.allreduce_events.append((e0, e1))
+        else:
+            self.bucket.all_reduce(self.group)
         return self.bucket.loss
 
     def apply_update(self):

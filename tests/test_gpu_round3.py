@@ -289,3 +289,18 @@ def test_bench_two_ranks(torch_cuda):
     # whole-job aggregate: all ranks' rod-steps over the slowest rank's time (ms_per_step is rounded to 1e-4 ms)
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 1024 * 20 / (rec["ms_per_step"] * 20e-3)) < 2e-2 * rec["value"]
     assert "roofline" in rec and rec["unit"] == "rod-steps/s"
+    assert rec["timed_chunks"]["n"] == 5 and len(rec["timed_chunks"]["wall_ms"]) == 5
+    # round 4: the driver's N > 1 command also runs BASELINE cfg4 data parallel - 4096 trajectories over the ranks, ONE
+    # all-reduce of the flat gradient + loss buffer per epoch (gloo here, RCCL under the nccl backend), 50 epochs - and
+    # rank 0 repeats the global batch alone: same loss curve
+    dp = rec["extra"]["train_dp"]
+    assert "error" not in dp, dp
+    assert dp["ranks_seen"] == 2 and dp["trajectories"] == 4096 and dp["trajectories_per_rank"] == 2048
+    assert dp["epochs"] == 50 and dp["floats"] == 28 * 512 + 512 + 512 * 25 + 25 + 1
+    assert dp["allreduce_us"] is not None and dp["allreduce_us"] > 0 and dp["data_unconverged"] == 0
+    assert np.isfinite(dp["loss_first"]) and dp["loss_last"] < dp["loss_first"]
+    chk = dp["single_rank_check"]
+    assert chk["ok"] and chk["rel_dev_first"] < 2e-5, chk
+    # strong scaling beside the default weak mode: 1024 rods split over the two ranks
+    st = rec["extra"]["strong_scaling"]
+    assert st["rods_per_gpu"] == 512 and st["unconverged"] == 0 and st["value"] > 0
