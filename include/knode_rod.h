@@ -19,7 +19,14 @@
  *    name ends in _host; `stream` is a hipStream_t passed as void* (NULL = the
  *    null stream).  Calls are asynchronous on that stream.
  *  - one handle per (device, parameter set); a handle is not thread-safe,
- *    distinct handles are.
+ *    distinct handles are.  A handle may be used with several streams from
+ *    ONE host thread: its calls share per-handle scratch (predictor images,
+ *    resume steps of the two-launch simulate, history workspaces, loss
+ *    partials), so a call on another stream than the handle's previous call
+ *    is made to wait for everything that call's stream had queued (an event,
+ *    no host synchronisation) - calls on one handle never overlap on the
+ *    device; use one handle per stream for concurrency.  The current HIP
+ *    device of the calling thread must be the handle's (KR_E_ARG otherwise).
  *  - dtype selects the arithmetic type of the call: KR_F32 or KR_F64.  All
  *    floating-point array arguments of a call have that element type.
  *

@@ -4,6 +4,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
+#include <utility>
 
 #include "kr_internal.hpp"
 
@@ -27,6 +30,40 @@ int ensure_ws(kr_handle* h, size_t bytes) {
   size_t want = bytes + bytes / 4;
   KR_HIP(hipMalloc(&h->ws, want));
   h->ws_bytes = want;
+  return KR_OK;
+}
+
+int order_stream(kr_handle* h, hipStream_t s) {
+  int dev = -1;
+  if (hipGetDevice(&dev) == hipSuccess && dev != h->device) {
+    set_error("the current HIP device (" + std::to_string(dev) + ") is not the one the handle was created on (" +
+              std::to_string(h->device) + "): call hipSetDevice first");
+    return KR_E_ARG;
+  }
+  if (h->have_last_stream && h->last_stream != s) {
+    if (!h->order_event) KR_HIP(hipEventCreateWithFlags(&h->order_event, hipEventDisableTiming));
+    if (hipEventRecord(h->order_event, h->last_stream) == hipSuccess) {
+      KR_HIP(hipStreamWaitEvent(s, h->order_event, 0));
+    } else {  // the previous stream is gone (destroyed by its owner): whatever ran on it has to be complete the hard way
+      (void)hipGetLastError();
+      KR_HIP(hipDeviceSynchronize());
+    }
+  }
+  h->last_stream = s;
+  h->have_last_stream = true;
+  return KR_OK;
+}
+
+int dyn_lds(const void* kern, size_t smem) {
+  if (smem <= 48 * 1024) return KR_OK;
+  int dev = 0;
+  KR_HIP(hipGetDevice(&dev));
+  static thread_local std::map<std::pair<const void*, int>, size_t> configured;
+  size_t& cur = configured[{kern, dev}];
+  if (smem > cur) {
+    KR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    cur = smem;
+  }
   return KR_OK;
 }
 
@@ -215,12 +252,12 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
       int rcp = ensure_pred(h, B * img_w);
       if (rcp) return rcp;
       sa.pred_io = static_cast<double*>(h->pred_buf);
-      sa.pred_load = h->pred_valid_B == B && h->pred_valid_W == img_w;
+      sa.pred_load = h->pred_valid_B == B && h->pred_valid_W == img_w && h->pred_valid_nn == (use_nn ? 1 : 0);
     }
     const int rc = launch_sim_persistent<T>(h, scheme, use_nn, sa, s);
     if (rc != 1) {
       h->last_sim_path = 2;
-      if (rc == KR_OK && sa.pred_io) { h->pred_valid_B = B; h->pred_valid_W = img_w; }
+      if (rc == KR_OK && sa.pred_io) { h->pred_valid_B = B; h->pred_valid_W = img_w; h->pred_valid_nn = use_nn ? 1 : 0; }
       return rc;
     }
   }
@@ -236,7 +273,8 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
       pred = static_cast<double*>(h->pred_buf);
     }
   }
-  const bool resume = pred && h->keep_predictor && h->pred_valid_B == B && h->pred_valid_W == img_w;
+  const bool resume = pred && h->keep_predictor && h->pred_valid_B == B && h->pred_valid_W == img_w &&
+                      h->pred_valid_nn == (use_nn ? 1 : 0);
   for (int64_t t = 0; t < T_steps; ++t) {
     // knode.py:65-66,76-77: before the first step y_prev = y (unless the caller hands over the state before)
     const int64_t ic = ring ? t % 3 : t;
@@ -259,7 +297,7 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
   }
   // the image is current only if the multiple-shooting kernel took the steps (launch_step decides)
   if (pred) h->pred_valid_B = (T_steps > 0 && h->last_sim_path == 1) ? B : (T_steps > 0 ? 0 : h->pred_valid_B);
-  if (pred && T_steps > 0) h->pred_valid_W = img_w;
+  if (pred && T_steps > 0) { h->pred_valid_W = img_w; h->pred_valid_nn = use_nn ? 1 : 0; }
   return KR_OK;
 }
 
@@ -472,6 +510,7 @@ int kr_destroy(kr_handle* h) {
   if (h->resume_buf) (void)hipFree(h->resume_buf);
   if (h->hist_ws) (void)hipFree(h->hist_ws);
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
+  if (h->order_event) (void)hipEventDestroy(h->order_event);
   delete h;
   return KR_OK;
 }
@@ -496,6 +535,7 @@ int kr_mlp_eval_batch(kr_handle* h, int64_t Q, const void* x, void* out, int dty
   if (Q == 0) return KR_OK;
   KR_CHECK_PTR(x); KR_CHECK_PTR(out);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   return dtype == KR_F32 ? launch_mlp_eval<float>(h, Q, (const float*)x, (float*)out, s)
                          : launch_mlp_eval<double>(h, Q, (const double*)x, (double*)out, s);
 }
@@ -504,6 +544,7 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
                const float* const* b, int src_on_device, void* stream) {
   KR_CHECK_H(h);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   KR_HIP(hipStreamSynchronize(s));
   free_mlp(h);
   if (n_layers == 0) return KR_OK;
@@ -685,6 +726,7 @@ int kr_ode_batch(kr_handle* h, int64_t Q, const void* y, const void* yh, const v
   if (Q == 0) return KR_OK;
   KR_CHECK_PTR(y); KR_CHECK_PTR(yh); KR_CHECK_PTR(zh); KR_CHECK_PTR(tf); KR_CHECK_PTR(dys); KR_CHECK_PTR(z);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   if (dtype == KR_F32)
     return launch_ode_batch<float>(h, Q, (const float*)y, (const float*)yh, (const float*)zh, (const float*)tf,
                                    (float*)dys, (float*)z, use_nn, s);
@@ -697,7 +739,8 @@ int kr_ode_batch(kr_handle* h, int64_t Q, const void* y, const void* yh, const v
   KR_CHECK_DTYPE(dtype);                           \
   if ((B) < 0) { set_error("B < 0"); return KR_E_ARG; } \
   if ((B) == 0) return KR_OK;                      \
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s = static_cast<hipStream_t>(stream); \
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
 
 int kr_state_init_straight(kr_handle* h, int64_t B, void* state, int dtype, void* stream) {
   KR_BATCH_PROLOGUE(B);

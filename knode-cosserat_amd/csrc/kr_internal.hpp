@@ -70,6 +70,7 @@ struct kr_handle {
   int keep_predictor = 0;     // kr_simulate_batch resumes from / leaves behind the predictor image (option)
   int64_t pred_valid_B = 0;   // batch size the image in pred_buf was written for (0: none)
   int pred_valid_W = 1;       // ... and the wavefronts per rod of the kernel that wrote it
+  int pred_valid_nn = 0;      // ... and whether the MLP was on (the image layout depends on the predictor's tap count)
   size_t ws_bytes = 0;
   int lds_limit = 160 * 1024;
   int ms_mode = -1;          // multiple-shooting step kernel: -1 auto (by batch size), 0 off, 1 forced
@@ -93,11 +94,23 @@ struct kr_handle {
   size_t resume_cap = 0;
   void* hist_ws = nullptr;     // history records [B][N][12] of the several-wavefront persistent kernel with the MLP on
   size_t hist_ws_cap = 0;
+  // Stream ordering of the handle's scratch (ws, pred_buf, resume_buf, hist_ws, loss_scratch are shared by its calls):
+  // a call on another stream than the previous one first waits for everything queued on that one (kr::order_stream)
+  hipStream_t last_stream = nullptr;
+  bool have_last_stream = false;
+  hipEvent_t order_event = nullptr;
 };
 
 namespace kr {
 
 int ensure_ws(kr_handle* h, size_t bytes);
+// Makes work queued on `s` from here on run after everything the handle's previous calls queued on ANOTHER stream (an
+// event on that stream's tail; nothing at all when the stream did not change).  Every entry point that launches calls it.
+int order_stream(kr_handle* h, hipStream_t s);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for a kernel that needs more than 48 KB of dynamic LDS, once per
+// (host thread, device, kernel, size): the attribute belongs to the device's copy of the kernel, so the cache is keyed
+// by the current device too.  The prepare_* functions go through the same cache, so the first timed launch finds it set.
+int dyn_lds(const void* kern, size_t smem);
 
 template <typename T>
 inline const RodConst<T>& consts(kr_handle* h);

@@ -29,6 +29,7 @@ namespace kr {
 #ifndef KR_MS_UNROLL
 #define KR_MS_UNROLL 2  // grid points per trip of the non-storing sweep loop (lets the scheduler overlap neighbours)
 #endif
+constexpr int kMsUnroll = KR_MS_UNROLL;  // (a constant, not the macro, in the pragma: -save-temps compiles the preprocessed text)
 constexpr int MS_P = 4;
 constexpr int MS_WPB = 4;  // wavefronts (= rods) per workgroup: the CU puts the 4 waves of a workgroup on its 4 SIMDs
 
@@ -488,7 +489,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
         if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase, true);
       } else {
         if constexpr (SCHEME == KR_EULER) {
-#pragma unroll KR_MS_UNROLL
+#pragma unroll kMsUnroll
           for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t, true);
         } else {
           for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t, true);
@@ -1514,7 +1515,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
       wave_sync();
       if (lane < 6) L.Xs[0 * MS_YP + 7 + lane] = A.G[rod * 6 + lane];
       wave_sync();
+      const int it_plain = it;  // `iters` reports the plain and the damped phase together (knode_rod.h)
       status = ss_newton_damped<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it);
+      it += it_plain;
     }
     ms_pred_update<T>(Q, order, status, A.pred_limit, lane, L.Xs, stamps);
     Q.kappa = S.kappa;
@@ -1538,7 +1541,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB) void ms_step_kernel(const RodConst<T
     if (status != KR_ST_CONVERGED) {  // damped single shooting from the caller's guess
       if (lane < 6) L.Xs[0 * MS_YP + 7 + lane] = A.G[rod * 6 + lane];
       wave_sync();
+      const int it_plain = it;  // `iters` reports the plain and the damped phase together (knode_rod.h)
       status = ss_newton_damped<T, DIAG, SCHEME, HS, false, NN>(Pc, M, L, R, lane, C, S, it);
+      it += it_plain;
     }
   }
   if (lane < 6) A.G[rod * 6 + lane] = L.Xs[0 * MS_YP + 7 + lane];
@@ -1686,7 +1691,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
     if (status != KR_ST_CONVERGED) {  // plain Newton failed from the warm start too: damped single shooting from there
       if (lane < 6) L.Xs[0 * MS_YP + 7 + lane] = Gguess;
       wave_sync();
+      const int it_plain = it;  // `iters` reports the plain and the damped phase together (knode_rod.h)
       status = ss_newton_damped<T, DIAG, SCHEME, HS, true, NN>(Pc, M, L, R, lane, C, S, it);
+      it += it_plain;
     }
     if (lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
     ms_pred_update<T>(Q, order, status, A.predictor, lane, L.Xs, stamps);
@@ -1737,12 +1744,7 @@ static int launch_ms_inst(const RodConst<T>& P, const MlpDev<T>& M, const StepAr
   const int wpb = ms_wpb<T, hs_phys<T>()>(P.N, NN, lds_limit);
   if (wpb <= 0) { set_error("multiple-shooting kernel: history of N grid points does not fit in LDS"); return KR_E_ARG; }
   const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, false, NN, wpb);
-  static thread_local size_t configured = 0;
-  if (smem > 48 * 1024 && smem > configured) {
-    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
-    configured = smem;
-  }
+  if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), smem)) return rc_lds_;
   hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + wpb - 1) / wpb)), dim3(WAVE * wpb), smem, s, P, a, M);
   KR_HIP(hipGetLastError());
   return KR_OK;
@@ -1777,21 +1779,23 @@ static int launch_ms_nn(kr_handle* h, int scheme, const StepArgs<T>& a, hipStrea
   set_error("unknown scheme");
   return KR_E_ARG;
 }
+// The one-launch-per-step kernels WITH the MLP live in their own translation units (kr_msn_f32.hip / kr_msn_f64.hip,
+// kr_msn_impl.hpp): they are the most register-starved kernels of the library, and hipcc 7.2 places ordinary VGPR
+// spills inside the whole-wave-mode brackets it opens to reach its SGPR-spill registers there (DESIGN.md section 4,
+// tools/wwm_spill_scan.py).  Those units are compiled with SGPR spills going to memory instead of VGPR lanes, which
+// removes the brackets altogether.
+template <typename T>
+int launch_ms_step_nn(kr_handle* h, int scheme, const StepArgs<T>& a, hipStream_t s);
 template <typename T>
 static int launch_ms(kr_handle* h, int scheme, int use_nn, const StepArgs<T>& a, hipStream_t s) {
   h->last_sim_path = 1;
-  return use_nn ? launch_ms_nn<T, true>(h, scheme, a, s) : launch_ms_nn<T, false>(h, scheme, a, s);
+  return use_nn ? launch_ms_step_nn<T>(h, scheme, a, s) : launch_ms_nn<T, false>(h, scheme, a, s);
 }
 template <typename T, bool DIAG, int SCHEME, bool NN, int OCC = 1>
 static int launch_ms_sim_inst(const RodConst<T>& P, const MlpDev<T>& M, const SimArgs<T>& a, hipStream_t s) {
   auto kern = ms_sim_kernel<T, DIAG, SCHEME, hs_phys<T>(), NN, OCC>;
   const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, true, NN);
-  static thread_local size_t configured = 0;
-  if (smem > 48 * 1024 && smem > configured) {
-    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
-    configured = smem;
-  }
+  if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), smem)) return rc_lds_;
   hipLaunchKernelGGL(kern, dim3((unsigned)((a.B + MS_WPB - 1) / MS_WPB)), dim3(WAVE * MS_WPB), smem, s, P, a, M);
   KR_HIP(hipGetLastError());
   return KR_OK;
@@ -1868,8 +1872,7 @@ int prepare_ms_sim(kr_handle* h) {
   hipFuncAttributes fa;
   KR_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
   const size_t smem = ms_lds_bytes<T, hs_phys<T>()>(P.N, true);
-  if (smem > 48 * 1024 && smem <= (size_t)h->lds_limit)
-    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  if (smem <= (size_t)h->lds_limit) if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), smem)) return rc_lds_;
   return KR_OK;
 }
 }  // namespace kr

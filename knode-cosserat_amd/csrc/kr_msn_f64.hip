@@ -1,0 +1,7 @@
+// double instantiation of the one-launch-per-step multiple-shooting kernels with the MLP on (kr_msn_impl.hpp)
+#define KR_SIM_T double
+#define KR_MS_NO_INST
+#include "kr_msn_impl.hpp"
+namespace kr {
+template int launch_ms_step_nn<double>(kr_handle*, int, const StepArgs<double>&, hipStream_t);
+}

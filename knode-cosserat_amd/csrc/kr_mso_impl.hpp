@@ -719,7 +719,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
 
   if (lane < 6) A.G[rod * 6 + lane] = Gguess;
   if (lane == 0 && A.resume) A.resume[rod] = (int32_t)resume_at;
-  if (img) {
+  // A rod handed over to the take-over kernel does not save: that kernel rebuilds the predictor from the stored states
+  // when it resumes (t0 > 0) and, for a rod that gave up at step 0, must still find the image of the PREVIOUS call
+  // (not one that already contains the rejected step); it saves its own image at the end.
+  if (img && (resume_at >= T_steps || !A.resume)) {
     Q.kappa = kappa;
     ms_pred_save<T>(Q, img, lane);
   }
@@ -749,11 +752,11 @@ int prepare_mso_sim(kr_handle* h, int64_t B) {
   if (sizeof(T) == 4 && B > 1024 && 2 * smem <= (size_t)h->lds_limit) {
     auto k2 = mso_sim_kernel<T, true, HS, 2>;
     KR_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k2)));
-    if (smem > 48 * 1024) KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(k2), smem)) return rc_lds_;
   } else {
     auto k1 = mso_sim_kernel<T, true, HS, 1>;
     KR_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k1)));
-    if (smem > 48 * 1024) KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(k1), smem)) return rc_lds_;
   }
   return KR_OK;
 }
@@ -770,24 +773,14 @@ int launch_mso_sim(kr_handle* h, const SimArgs<T>& a, hipStream_t s) {
     // fp32, more rods than SIMDs, and two workgroups fit the LDS of a CU: two wavefronts per SIMD
     if (a.B > 1024 && 2 * smem <= (size_t)h->lds_limit) {
       auto kern2 = mso_sim_kernel<T, true, HS, 2>;
-      static thread_local size_t configured2 = 0;
-      if (smem > 48 * 1024 && smem > configured2) {
-        KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)smem));
-        configured2 = smem;
-      }
+      if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern2), smem)) return rc_lds_;
       hipLaunchKernelGGL(kern2, grid, block, smem, s, P, a);
       KR_HIP(hipGetLastError());
       return KR_OK;
     }
   }
   auto kern = mso_sim_kernel<T, true, HS, 1>;
-  static thread_local size_t configured = 0;
-  if (smem > 48 * 1024 && smem > configured) {
-    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
-    configured = smem;
-  }
+  if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), smem)) return rc_lds_;
   hipLaunchKernelGGL(kern, grid, block, smem, s, P, a);
   KR_HIP(hipGetLastError());
   return KR_OK;

@@ -924,7 +924,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
       for (int t = 0; t < R.sbase; ++t) point(std::true_type{}, R.s_i + t, true);
       if (R.len_i > R.sbase) point(std::true_type{}, R.s_i + R.sbase, true);
     } else {
-#pragma unroll KR_MS_UNROLL
+#pragma unroll kMsUnroll
       for (int t = 0; t < R.sbase; ++t) point(std::false_type{}, R.s_i + t, true);
       if (R.len_i > R.sbase) point(std::false_type{}, R.s_i + R.sbase, true);
     }
@@ -1312,7 +1312,9 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       if (wave == 0) {
         if (lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];
         wave_sync();
+        const int it_plain = it;  // `iters` reports the plain and the damped phase together (knode_rod.h)
         status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it, L.hist, nn);
+        it += it_plain;
         if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
       }
       __syncthreads();
@@ -1349,7 +1351,9 @@ __global__ __launch_bounds__(WAVE * W) void msw_step_kernel(const RodConst<T> Pc
       if (wave == 0) {
         if (lane < 6) L.Xs[0 * 19 + 7 + lane] = A.G[rod * 6 + lane];
         wave_sync();
+        const int it_plain = it;  // `iters` reports the plain and the damped phase together (knode_rod.h)
         status = msw_ss_damped<T, DIAG, W>(Pc, L, lane, fconst, S, it, L.hist, nn);
+        it += it_plain;
         if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
       }
       __syncthreads();
@@ -1521,7 +1525,9 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       if (wave == 0) {
         if (lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;
         wave_sync();
+        const int it_plain = it;  // `iters` reports the plain and the damped phase together (knode_rod.h)
         status = msw_ss_damped<T, DIAG, W, NN, OCC - 1>(Pc, L, lane, fconst, S, it, hist, nn);
+        it += it_plain;
         if (lane == 0) { L.red[0] = (T)status; L.red[1] = (T)it; }
       }
       __syncthreads();
@@ -1545,11 +1551,7 @@ template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1, int HM = N
 static int launch_msw_sim_inst(const RodConst<T>& P, const MlpDev<T>& M, const SimArgs<T>& a, hipStream_t s) {
   auto kern = msw_sim_kernel<T, DIAG, W, NN, OCC, HM>;
   const size_t smem = sizeof(T) * msw_sim_lds_elems<T, W>(P.N, NN, HM);
-  static thread_local size_t configured = 0;
-  if (smem > 48 * 1024 && smem > configured) {
-    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = smem;
-  }
+  if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), smem)) return rc_lds_;
   hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * W), smem, s, P, a, M);
   KR_HIP(hipGetLastError());
   return KR_OK;
@@ -1614,11 +1616,7 @@ template <typename T, bool DIAG, int W>
 static int launch_msw_inst(const RodConst<T>& P, const StepArgs<T>& a, hipStream_t s) {
   auto kern = msw_step_kernel<T, DIAG, W>;
   const size_t smem = msw_lds_bytes<T, W>(P.N);
-  static thread_local size_t configured = 0;
-  if (smem > 48 * 1024 && smem > configured) {
-    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = smem;
-  }
+  if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), smem)) return rc_lds_;
   hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * W), smem, s, P, a);
   KR_HIP(hipGetLastError());
   return KR_OK;

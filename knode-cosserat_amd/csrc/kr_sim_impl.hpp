@@ -640,12 +640,7 @@ template <typename T, bool DIAG, int SCHEME, bool HIST_LDS, bool NN, int HS>
 static int launch_step_inst(const RodConst<T>& P, const MlpDev<T>& M, const StepArgs<T>& a, size_t smem,
                             hipStream_t s) {
   auto kern = step_kernel<T, DIAG, SCHEME, HIST_LDS, NN, HS>;
-  static thread_local size_t configured = 0;
-  if (smem > 48 * 1024 && smem > configured) {
-    KR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
-    configured = smem;
-  }
+  if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), smem)) return rc_lds_;
   const int grid = (int)((a.B + RPW - 1) / RPW);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), smem, s, P, a, M);
   KR_HIP(hipGetLastError());

@@ -435,6 +435,7 @@ int kr_next_segment_physics(kr_handle* h, int64_t S, int K, const void* Gs, cons
   const int need = hist ? 53 : 28;
   if (in_pad < need) { set_error("in_pad smaller than the MLP input width"); return KR_E_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   const int64_t rows = S * K;
   int grid = (int)((rows + 255) / 256);
   if (grid > 4096) grid = 4096;
@@ -478,6 +479,7 @@ int kr_mlp_forward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, c
   }
   if (Q > (int64_t)1 << 30) { set_error("Q too large"); return KR_E_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   if (h->fused_mlp && fused_mlp_supported(n_layers, dims, acts, in_pad)) {
     KR_CHECK_PTR(ws);
     return fused_mlp_forward(Q, n_layers, dims, acts, W, b, x, out, ws, s);
@@ -516,6 +518,7 @@ int kr_mlp_backward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, 
   if (Q < 0) { set_error("Q < 0"); return KR_E_ARG; }
   KR_CHECK_PTR(acts); KR_CHECK_PTR(W); KR_CHECK_PTR(dW); KR_CHECK_PTR(db);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   for (int k = 0; k < n_layers; ++k) {
     KR_CHECK_PTR(dW[k]); KR_CHECK_PTR(db[k]);
     if (!h->grad_accumulate) {  // option "mlp_grad_accumulate": the caller keeps the buffers zeroed (kr_adam_step does)
@@ -590,6 +593,7 @@ int kr_loss_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, const flo
   if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
   KR_CHECK_PTR(loss);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   KR_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
   if (S == 0 || K == 0) return KR_OK;
   KR_CHECK_PTR(base); KR_CHECK_PTR(out); KR_CHECK_PTR(target); KR_CHECK_PTR(idx); KR_CHECK_PTR(pred); KR_CHECK_PTR(dout);
@@ -610,6 +614,7 @@ int kr_gather_targets(kr_handle* h, int64_t S, int K, const float* target, const
   if (S == 0 || K == 0) return KR_OK;
   KR_CHECK_PTR(target); KR_CHECK_PTR(idx); KR_CHECK_PTR(rows);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   const int64_t n = S * K * 25;
   int grid = (int)((n + 255) / 256);
   if (grid > 4096) grid = 4096;
@@ -624,6 +629,7 @@ int kr_loss_rows_fwd_bwd(kr_handle* h, int64_t S, int K, const float* base, cons
   if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
   KR_CHECK_PTR(loss);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   if (!h->grad_accumulate) KR_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
   if (S == 0 || K == 0) return KR_OK;
   KR_CHECK_PTR(base); KR_CHECK_PTR(out); KR_CHECK_PTR(target_rows); KR_CHECK_PTR(dout);
@@ -649,6 +655,7 @@ int kr_mlp_forward_loss(kr_handle* h, int64_t S, int K, int n_layers, const int3
   if (rc) return rc;
   KR_CHECK_PTR(loss);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   if (Q > 0 && h->fused_mlp && dims[n_layers] == 25 && acts && fused_mlp_supported(n_layers, dims, acts, in_pad)) {
     KR_CHECK_PTR(W); KR_CHECK_PTR(b); KR_CHECK_PTR(x); KR_CHECK_PTR(base); KR_CHECK_PTR(target_rows); KR_CHECK_PTR(dout);
     KR_CHECK_PTR(ws);
@@ -676,6 +683,7 @@ int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* ex
   KR_CHECK_PTR(grads);
   if (n) { KR_CHECK_PTR(params); KR_CHECK_PTR(exp_avg); KR_CHECK_PTR(exp_avg_sq); }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
   int grid = (int)((n_zero + 255) / 256);
   if (grid > 1024) grid = 1024;
@@ -696,6 +704,7 @@ int kr_adam_plateau_step(kr_handle* h, int64_t n, float* params, float* grads, f
   KR_CHECK_PTR(grads); KR_CHECK_PTR(sched);
   if (n) { KR_CHECK_PTR(params); KR_CHECK_PTR(exp_avg); KR_CHECK_PTR(exp_avg_sq); }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
   int grid = (int)((n_zero + 255) / 256);
   if (grid > 1024) grid = 1024;

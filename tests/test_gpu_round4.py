@@ -1,0 +1,131 @@
+"""GPU tests (``-m gpu``) added in round 4 for behaviour of the C ABI rather than a new kernel:
+
+  * one handle driven from two streams (the default two-launch simulate shares per-handle scratch: SimArgs::resume, history
+    workspaces, predictor images) - calls are ordered on the device, results equal the one-stream run;
+  * a predictor image left by an MLP-off call is not loaded by an MLP-on call of the same batch size (its layout depends
+    on the predictor's tap count);
+  * ``iters`` of ``kr_step_batch`` counts the plain AND the damped phase on every step kernel (knode_rod.h)."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from gpu_helpers import assert_path, expected_path, inject, make_robot, set_mode_env
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _sim(torch, h, ctl, maxit=0, use_nn=False):
+    B, T = ctl.shape[0], ctl.shape[1]
+    st = h.new_state(B, ctl.dtype, n_slots=T + 1)
+    h.init_straight(st[0])
+    G = torch.zeros((B, 6), dtype=ctl.dtype, device=DEV)
+    tip = torch.empty((B, T, 3), dtype=ctl.dtype, device=DEV)
+    status = torch.full((B, T), -1, dtype=torch.int32, device=DEV)
+    h.simulate(ctl, st, G, tip=tip, status=status, maxit=maxit, use_nn=use_nn)
+    return st, tip, status
+
+
+@pytest.mark.parametrize("maxit", [0, 2])
+def test_one_handle_two_streams(torch_cuda, monkeypatch, maxit):
+    """Two kr_simulate_batch calls of one handle queued back to back on DIFFERENT streams, default kernels (overlapped
+    launch + take-over launch, which hands the per-rod resume step through the handle's resume buffer).  With maxit = 2
+    rods are handed over at different steps in the two calls; unordered, call B's first kernel would overwrite the resume
+    steps call A's take-over kernel has not read yet.  The library orders the streams; both results equal their
+    one-stream runs bit for bit."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    set_mode_env(monkeypatch, "overlap")
+    r = make_robot(None, 100)
+    h = r._native()
+    B, T = 1024, 24
+    ctl_a = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 5), device=DEV).contiguous()
+    ctl_b = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 6) * 1.3, device=DEV).contiguous()
+    ref_a = _sim(torch, h, ctl_a, maxit)
+    ref_b = _sim(torch, h, ctl_b, maxit)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            got_a = _sim(torch, h, ctl_a, maxit)
+        with torch.cuda.stream(s2):
+            got_b = _sim(torch, h, ctl_b, maxit)
+        torch.cuda.synchronize()
+        for got, ref in ((got_a, ref_a), (got_b, ref_b)):
+            assert torch.equal(got[2], ref[2])
+            assert torch.equal(got[1], ref[1])
+            assert torch.equal(got[0][T], ref[0][T])
+    assert h.get_option("last_overlap") == 1
+
+
+def test_wrong_current_device_is_an_error(torch_cuda):
+    """The handle belongs to one device; a call from a thread whose current device is another one is refused instead of
+    launching into the wrong context (only checkable with more than one device - otherwise the positive path)."""
+    torch = torch_cuda
+    import krod_native as kn
+    r = make_robot(None, 20)
+    h = r._native()
+    st = h.new_state(2, torch.float64)
+    h.init_straight(st)
+    if torch.cuda.device_count() > 1:
+        with torch.cuda.device(1):
+            with pytest.raises(kn.KrError):
+                h.init_straight(st)
+    torch.cuda.synchronize()
+
+
+def test_predictor_image_is_keyed_on_the_mlp(torch_cuda, monkeypatch):
+    """keep_predictor: an MLP-off call leaves a 3-tap predictor image; the MLP-on call of the same batch size that follows
+    uses 5 taps and another layout - it must rebuild its predictor, i.e. give what a fresh handle gives."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    set_mode_env(monkeypatch, "persistent")
+    N, B, T = 40, 8, 12
+    mlp = orc.make_mlp([28, 64, 64, 25], "elu", seed=7)
+    ctl = torch.as_tensor(orc.batch_sine_controls(B, T, 0.05, 9), device=DEV).contiguous()
+    r = make_robot(None, N)
+    inject(r, mlp)
+    h = r._native()
+    fresh = _sim(torch, h, ctl, use_nn=True)
+    r2 = make_robot(None, N)
+    inject(r2, mlp)
+    h2 = r2._native()
+    h2.set_option("keep_predictor", 1)
+    _sim(torch, h2, ctl, use_nn=False)          # leaves an MLP-off image for B rods
+    again = _sim(torch, h2, ctl, use_nn=True)
+    torch.cuda.synchronize()
+    assert torch.equal(again[2], fresh[2]) and int((fresh[2] != 0).sum()) == 0
+    assert torch.equal(again[1], fresh[1])
+
+
+@pytest.mark.parametrize("mode,W", [("single", 1), ("multi", 1), ("multi", 2)])
+def test_iters_counts_both_phases(torch_cuda, monkeypatch, mode, W):
+    """kr_step_batch with an iteration cap of 2 from the straight rod and a large tension jump: plain Newton hits the cap,
+    the damped fallback finishes the step - `iters` reports more than the cap on every step kernel (plain + damped), and
+    the same status."""
+    torch = torch_cuda
+    N = 100
+    set_mode_env(monkeypatch, mode, waves_per_rod=W)
+    r = make_robot(None, N)
+    h = r._native()
+    B = 4
+    st = h.new_state(B, torch.float64, n_slots=2)
+    h.init_straight(st[0])
+    G = torch.zeros((B, 6), dtype=torch.float64, device=DEV)
+    tens = torch.tensor([[9.0, 5.0, 5.0, 9.0]] * B, dtype=torch.float64, device=DEV)
+    status = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+    iters = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    h.step(st[0], st[0], st[1], G, tens, maxit=2, status=status, iters=iters)
+    torch.cuda.synchronize()
+    assert_path(h, expected_path(mode, N), W) if W == 1 else None
+    if W > 1:
+        assert h.get_option("last_waves_per_rod") == W
+    assert int(status.max()) <= 1
+    assert int(iters.min()) > 2, iters.tolist()   # 2 plain iterations + at least one damped one

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden
+from conftest import PKG, ROOT, load_golden
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -419,3 +419,24 @@ _ZN2kr6kernelEv:
     clean.write_text(asm.read_text().replace("	v_mov_b32_e32 v255, v250\n	scratch_store_dwordx4 off, v[2:5], off offset:608 ; 16-byte Folded Spill\n", "	v_mov_b32_e32 v255, v250\n"))
     r = subprocess.run([sys.executable, tool, str(clean)], capture_output=True, text=True)
     assert r.returncode == 0 and "0 spill(s)" in r.stdout, r.stdout
+
+
+def test_shipped_assembly_has_no_spill_in_whole_wave_brackets():
+    """The build keeps the gfx950 assembly of every translation unit (csrc/Makefile, -save-temps of the same compile
+    that made the object) and runs the scanner as a build gate; here it runs again over what the build left, and every
+    unit of the Makefile's SRCS list must be there (the gate cannot be skipped by not producing the assembly)."""
+    import re
+    import subprocess
+    import sys
+    mk = open(os.path.join(PKG, "csrc", "Makefile")).read()
+    srcs = re.search(r"^SRCS = (.*)$", mk, re.M).group(1).split()
+    asm_dir = os.path.join(PKG, "lib", "asm")
+    if not os.path.isdir(asm_dir):
+        pytest.skip("no build in this tree (the assembly is written next to the objects; the GPU box only gets the .so)")
+    files = [os.path.join(asm_dir, s.replace(".hip", ".s")) for s in srcs]
+    missing = [f for f in files if not os.path.exists(f)]
+    assert not missing, missing
+    assert "kr_msn_f64.hip" in srcs and "-amdgpu-spill-sgpr-to-vgpr=0" in mk
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wwm_spill_scan.py")] + files,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "0 spill(s)" in r.stdout, r.stdout[-2000:]
