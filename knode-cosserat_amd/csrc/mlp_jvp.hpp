@@ -243,21 +243,25 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
 // and are put back into their address spaces first - flat loads would serialise LDS and global traffic.
 // VAR: a second copy of the function for the kernels built for two wavefronts per SIMD (the register limit of a kernel
 // reaches its callees only if all callers of a function agree on it)
+// The network descriptor arrives as SCALAR ARGUMENTS (29 dwords: the AMDGPU calling convention passes the first 32 in
+// VGPRs): as one by-value struct it went through private memory - 26 scratch stores in the caller, as many scratch loads
+// and a full memory round trip at the head of every evaluation.
+// not_tail_called: a call site the optimiser marks `tail` (possible now that no argument lives in the caller's frame)
+// switches off LLVM's "no callee-saved registers" treatment of this internal function, and the callee then saves and
+// restores ~170 VGPRs through scratch memory on every evaluation.
 template <typename T, int ACT, int VAR = 0>
-__device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_generic, int lane) {
-  gf4p wq[3];
-  gfp bq[3];
-  gbfp jq[3];
-  int kgs[3], ots[3], jkss[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    wq[k] = (gf4p)uni64((unsigned long long)netv.wq[k]);
-    bq[k] = (gfp)uni64((unsigned long long)netv.bq[k]);
-    jq[k] = (gbfp)uni64((unsigned long long)netv.j[k]);
-    kgs[k] = uni(netv.kg[k]); ots[k] = uni(netv.ot[k]); jkss[k] = uni(netv.jks[k]);
-  }
-  const int L = uni(netv.L);
-  const int ptab = uni(netv.ptab);
+__device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile(const float* wq0, const float* wq1, const float* wq2, const float* bq0,
+                                                       const float* bq1, const float* bq2, const bf16x8* j0, const bf16x8* j1,
+                                                       const bf16x8* j2, int kg1, int kg2, int ot0, int ot1, int jks1, int jks2,
+                                                       int Lv, int ptabv, T* scratch_generic, int lane) {
+  gf4p wq[3] = {(gf4p)uni64((unsigned long long)wq0), (gf4p)uni64((unsigned long long)wq1), (gf4p)uni64((unsigned long long)wq2)};
+  gfp bq[3] = {(gfp)uni64((unsigned long long)bq0), (gfp)uni64((unsigned long long)bq1), (gfp)uni64((unsigned long long)bq2)};
+  gbfp jq[3] = {(gbfp)uni64((unsigned long long)j0), (gbfp)uni64((unsigned long long)j1), (gbfp)uni64((unsigned long long)j2)};
+  const int kgs[3] = {2, uni(kg1), uni(kg2)};
+  const int ots[3] = {uni(ot0), uni(ot1), MM_OUT_T};
+  const int jkss[3] = {1, uni(jks1), uni(jks2)};
+  const int L = uni(Lv);
+  const int ptab = uni(ptabv);
   MJ_LDS unsigned char* sbase = (MJ_LDS unsigned char*)(unsigned)__builtin_amdgcn_readfirstlane(
       (int)(unsigned long long)(MJ_LDS unsigned char*)scratch_generic);
   MJ_LDS T* xb = (MJ_LDS T*)sbase;
@@ -419,6 +423,174 @@ __device__ __attribute__((noinline)) void mlp_jvp_tile(JvpNet netv, T* scratch_g
   mm_wave_sync();
 }
 
+// mlp_jvp_tile3: the evaluator for networks in -> H1 <= 64 -> H2 <= 64 -> 25 (every layer ONE chunk: BASELINE cfg3's
+// 28 -> 64 -> 64 -> 25) as its own function, so that its register allocation is its own (a function's footprint is the
+// maximum over its paths, and the caller spills around the call what the callee may clobber).
+// The network descriptor arrives as SCALAR ARGUMENTS (29 dwords: the AMDGPU calling convention passes the first 32 in
+// VGPRs): as one by-value struct it went through private memory - 26 scratch stores in the caller, as many scratch loads
+// and a full memory round trip at the head of every evaluation.
+// not_tail_called: a call site the optimiser marks `tail` (possible now that no argument lives in the caller's frame)
+// switches off LLVM's "no callee-saved registers" treatment of this internal function, and the callee then saves and
+// restores ~170 VGPRs through scratch memory on every evaluation.
+template <typename T, int ACT, int VAR = 0>
+__device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const float* wq0, const float* wq1, const float* wq2, const float* bq0,
+                                                       const float* bq1, const float* bq2, const bf16x8* j0, const bf16x8* j1,
+                                                       const bf16x8* j2, int kg1, int kg2, int ot0, int ot1, int jks1, int jks2,
+                                                       int Lv, int ptabv, T* scratch_generic, int lane) {
+  gf4p wq[3] = {(gf4p)uni64((unsigned long long)wq0), (gf4p)uni64((unsigned long long)wq1), (gf4p)uni64((unsigned long long)wq2)};
+  gfp bq[3] = {(gfp)uni64((unsigned long long)bq0), (gfp)uni64((unsigned long long)bq1), (gfp)uni64((unsigned long long)bq2)};
+  gbfp jq[3] = {(gbfp)uni64((unsigned long long)j0), (gbfp)uni64((unsigned long long)j1), (gbfp)uni64((unsigned long long)j2)};
+  const int kgs[3] = {2, uni(kg1), uni(kg2)};
+  const int ots[3] = {uni(ot0), uni(ot1), MM_OUT_T};
+  const int jkss[3] = {1, uni(jks1), uni(jks2)};
+  const int L = uni(Lv);
+  const int ptab = uni(ptabv);
+  MJ_LDS unsigned char* sbase = (MJ_LDS unsigned char*)(unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned long long)(MJ_LDS unsigned char*)scratch_generic);
+  MJ_LDS T* xb = (MJ_LDS T*)sbase;
+  MJ_LDS float* actp = (MJ_LDS float*)(sbase + mj_xb_bytes<T>());
+  MJ_LDS unsigned char* dreg = sbase + mj_xb_bytes<T>() + MJ_ACTP_BYTES;
+  const MJ_LDS bf16x8* dx = (const MJ_LDS bf16x8*)dreg;
+  MJ_LDS float* dout = (MJ_LDS float*)dreg;
+  const int lo_ = L == 2 ? 1 : 2;
+  const int q = lane >> 4, c = lane & 15, j4 = lane & 3;
+  const int dunit = 4 * ((lane >> 2) & 3) + (lane >> 4);  // unit of this lane inside a D tile
+
+  double obase[MM_OUT_T][2];  // two partial sums per output tile (4 independent accumulators for the matrix pipe)
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2) { obase[o2][0] = (double)bq[lo_][o2 * 64 + lane]; obase[o2][1] = 0.0; }
+  f32x4 ojvp[MM_OUT_T][4];
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ojvp[o2][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto zero_dh = [](f32x4 (&dh)[4][4]) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dh[o][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto out_layer = [&](const double (&h)[4], const f32x4 (&wo4)[4][MM_OUT_T], auto batched) {
+    // output tiles from a 64-unit chunk; even / odd k-groups into separate partial sums
+    double a4[4] = {obase[0][0], obase[1][0], obase[0][1], obase[1][1]};
+    double bvs[16];
+    if constexpr (decltype(batched)::value) chunk_operands(h, bvs);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double bv;
+        if constexpr (decltype(batched)::value) bv = bvs[4 * g + e];
+        else bv = chunk_operand(h, 4 * g + e);
+#pragma unroll
+        for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4((double)wo4[g][o2][e], bv, a4[2 * (g & 1) + o2]);
+      }
+    obase[0][0] = a4[0]; obase[1][0] = a4[1]; obase[0][1] = a4[2]; obase[1][1] = a4[3];
+  };
+
+  // base inputs as B operand: input 4 ks + (l >> 4) of sample l & 3 (the same in every block); k-step 7 is padding
+  double bin[8];
+#pragma unroll
+  for (int ks = 0; ks < MM_KS1; ++ks) bin[ks] = (double)xb[j4 * MJ_XB_LD + 4 * ks + q];
+  bin[7] = 0.0;
+
+  {
+    // in -> H1 (<= 64) -> H2 (<= 64) -> 25, everything one chunk (BASELINE cfg3's 28 -> 64 -> 64 -> 25): straight-line
+    // code.  (1) The JVP products of a layer are issued BETWEEN the base products of the same layer - they only depend
+    // on the previous layer's act' table.  (2) Weight fragments are requested ONE LAYER AHEAD instead of all at the top
+    // (sched_barrier keeps the scheduler from hoisting them back): the evaluator's register footprint is what the
+    // calling sweep kernel has to spill around every call, and what the compiler shuffles through AGPRs in here.
+    f32x4 w1[2][4], w2[4][4];
+    bf16x8 a1[1][4];
+    base_load<4, 2>(w1, wq[0], 2, 0, 0, lane);
+    jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
+    bf16x8 bdx[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bdx[s] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+    double h1[4], h2[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { h1[o] = (double)bq[0][o * 64 + lane]; h2[o] = (double)bq[1][o * 64 + lane]; }
+    base_load<4, 4>(w2, wq[1], 4, 0, 0, lane);
+    f32x4 dh[4][4];
+    zero_dh(dh);
+    // layer 1: 2 k-groups of the base product, 8 JVP products behind each
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h1[o] = mfma4((double)w1[g][o][e], bin[4 * g + e], h1[o]);
+#pragma unroll
+      for (int o = 2 * g; o < 2 * g + 2; ++o)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a2[2][4];
+    jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
+    chunk_activate<ACT>(h1, actp, lane);
+    mm_wave_sync();
+    bf16x8 b1[4][2];
+    jvp_scale_pack(dh, actp, lane, b1, ptab);
+    // layer 2: 4 k-groups of the base product (operands: swizzled blocks of h1), 8 JVP products behind each
+    zero_dh(dh);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double bv = chunk_operand(h1, 4 * g + e);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h2[o] = mfma4((double)w2[g][o][e], bv, h2[o]);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0][g], b1[s][0], dh[g][s], 0, 0, 0);
+        dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][g], b1[s][1], dh[g][s], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 wo4[4][MM_OUT_T];
+    bf16x8 ao[2][MM_OUT_T];
+    base_load<MM_OUT_T, 4>(wo4, wq[2], kgs[2], 0, 0, lane);
+    jvp_load<MM_OUT_T, 2>(ao, jq[2], jkss[2], 0, 0, lane);
+    chunk_activate<ACT>(h2, actp + 256, lane);
+    mm_wave_sync();
+    bf16x8 b2[4][2];
+    jvp_scale_pack(dh, actp + 256, lane, b2, ptab);
+    // output layer: even / odd k-groups into separate partial sums; 4 JVP products behind each k-group
+    {
+      double a4[4] = {obase[0][0], obase[1][0], obase[0][1], obase[1][1]};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double bv = chunk_operand(h2, 4 * g + e);
+#pragma unroll
+          for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4((double)wo4[g][o2][e], bv, a4[2 * (g & 1) + o2]);
+        }
+        const int ks = g >> 1, o2 = g & 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ojvp[o2][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[ks][o2], b2[s][ks], ojvp[o2][s], 0, 0, 0);
+      }
+      obase[0][0] = a4[0]; obase[1][0] = a4[1]; obase[0][1] = a4[2]; obase[1][1] = a4[3];
+    }
+  }
+  // results: base outputs over the input rows, J dx rows over the dx rows (every lane has read its operands; the
+  // sync orders the other lanes' reads before these writes)
+  mm_wave_sync();
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+    if (16 * o2 + dunit < 25) xb[j4 * MJ_XB_LD + 16 * o2 + dunit] = (T)(obase[o2][0] + obase[o2][1]);
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (16 * o2 + 4 * q < MJ_DOUT_LD)  // units 16 o2 + 4 q .. + 3 as one 16-byte store (28 .. 31 do not exist)
+        *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
+  mm_wave_sync();
+}
+
+
 // Per-lane wrapper.  iv / col: the lane's role (sub-interval of the wavefront 0..3, 0 = unperturbed); idle lanes pass
 // col = 0 and a copy of their interval's state.  zrow: the dx row a lane without a column zeroes (the rows no column
 // owns: every sample tile has 16, an interval 6 or 16 columns; -1 = lane layout 7 + 3 x 17 of kr_ms_impl.hpp).
@@ -475,15 +647,27 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
     }
   }
   mm_wave_sync();
-  JvpNet net = jvp_net<T>(M);
-  net.ptab = ptab;
+#define MJ_TILE_ARGS                                                                                                        \
+  M.wq[0], M.wq[1], M.wq[2], M.bq[0], M.bq[1], M.bq[2], reinterpret_cast<const bf16x8*>(M.jfrag[0]),                         \
+      reinterpret_cast<const bf16x8*>(M.jfrag[1]), reinterpret_cast<const bf16x8*>(M.jfrag[2]), M.kgroups[1], M.kgroups[2],  \
+      M.otiles[0], M.otiles[1], M.jksteps[1], M.jksteps[2], M.n_layers, ptab, scratch, lane
+  if (M.n_layers == 3 && M.otiles[1] == 4) {  // wave-uniform: one chunk per layer
+    switch (M.acts[0]) {
+      case KR_ACT_TANH: mlp_jvp_tile3<T, KR_ACT_TANH, VAR>(MJ_TILE_ARGS); break;
+      case KR_ACT_SOFTPLUS: mlp_jvp_tile3<T, KR_ACT_SOFTPLUS, VAR>(MJ_TILE_ARGS); break;
+      case KR_ACT_RELU: mlp_jvp_tile3<T, KR_ACT_RELU, VAR>(MJ_TILE_ARGS); break;
+      case KR_ACT_ELU: mlp_jvp_tile3<T, KR_ACT_ELU, VAR>(MJ_TILE_ARGS); break;
+      default: mlp_jvp_tile3<T, KR_ACT_NONE, VAR>(MJ_TILE_ARGS); break;
+    }
+  } else
   switch (M.acts[0]) {  // wave-uniform
-    case KR_ACT_TANH: mlp_jvp_tile<T, KR_ACT_TANH, VAR>(net, scratch, lane); break;
-    case KR_ACT_SOFTPLUS: mlp_jvp_tile<T, KR_ACT_SOFTPLUS, VAR>(net, scratch, lane); break;
-    case KR_ACT_RELU: mlp_jvp_tile<T, KR_ACT_RELU, VAR>(net, scratch, lane); break;
-    case KR_ACT_ELU: mlp_jvp_tile<T, KR_ACT_ELU, VAR>(net, scratch, lane); break;
-    default: mlp_jvp_tile<T, KR_ACT_NONE, VAR>(net, scratch, lane); break;
+    case KR_ACT_TANH: mlp_jvp_tile<T, KR_ACT_TANH, VAR>(MJ_TILE_ARGS); break;
+    case KR_ACT_SOFTPLUS: mlp_jvp_tile<T, KR_ACT_SOFTPLUS, VAR>(MJ_TILE_ARGS); break;
+    case KR_ACT_RELU: mlp_jvp_tile<T, KR_ACT_RELU, VAR>(MJ_TILE_ARGS); break;
+    case KR_ACT_ELU: mlp_jvp_tile<T, KR_ACT_ELU, VAR>(MJ_TILE_ARGS); break;
+    default: mlp_jvp_tile<T, KR_ACT_NONE, VAR>(MJ_TILE_ARGS); break;
   }
+#undef MJ_TILE_ARGS
   {
     const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);
     constexpr int NB = (25 + n - 1) / n;

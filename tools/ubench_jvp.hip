@@ -49,7 +49,7 @@ static void stamps(const char* name, int iters) {
 }
 #endif
 template <typename T>
-void run(const char* name, std::vector<int> dims, int blocks) {
+void run(const char* name, std::vector<int> dims, int blocks, int act = KR_ACT_ELU) {
   const int L = (int)dims.size() - 1;
   MlpDev<T> M{};
   M.n_layers = L; M.mfma_ok = 1; M.jvp_ok = 1;
@@ -77,7 +77,7 @@ void run(const char* name, std::vector<int> dims, int blocks) {
     (void)hipMalloc(&w, 16 * tiles * kg * 64); fill(w, 16 * tiles * kg * 64, false);
     (void)hipMalloc(&b, 4 * tiles * 64); fill(b, 4 * tiles * 64, false);
     (void)hipMalloc(&j, 16 * tiles * jks * 64); fill(j, 16 * tiles * jks * 64, true);
-    M.wq[kk] = w; M.bq[kk] = b; M.kgroups[kk] = kg; M.otiles[kk] = tiles; M.acts[kk] = last ? KR_ACT_NONE : KR_ACT_ELU;
+    M.wq[kk] = w; M.bq[kk] = b; M.kgroups[kk] = kg; M.otiles[kk] = tiles; M.acts[kk] = last ? KR_ACT_NONE : act;
     M.jfrag[kk] = j; M.jksteps[kk] = jks;
     M.dims[kk] = dims[kk]; prev = tiles;
   }
@@ -100,6 +100,9 @@ int main() {
     run<double>("f64 28-64-64-25", {28, 64, 64, 25}, blocks);
     run<float>("f32 28-64-64-25", {28, 64, 64, 25}, blocks);
   }
+  run<double>("f64 28-64-64-25 RELU", {28, 64, 64, 25}, 256, KR_ACT_RELU);
+  run<double>("f64 28-64-64-25 NONE", {28, 64, 64, 25}, 256, KR_ACT_NONE);
+  run<double>("f64 28-64-64-25 TANH", {28, 64, 64, 25}, 256, KR_ACT_TANH);
   run<double>("f64 28-64-25", {28, 64, 25}, 256);
   run<double>("f64 28-512-25", {28, 512, 25}, 256);
   return 0;
