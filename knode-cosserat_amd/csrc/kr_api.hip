@@ -710,6 +710,43 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
       }
       prev_tiles = tiles;
     }
+    mf.f32_ok = md.f32_ok = 0;
+    if (n_layers == 3 && dims[1] <= 64 && dims[2] <= 64) {
+      // fp32 base chain (mlp_jvp_tile3f): row l of a layer's weight matrix on lane l; the output layer's 32 rows twice,
+      // rows 32..63 with the second half of its k range
+      const int groups[3] = {7, 16, 8};
+      for (int k = 0; k < 3; ++k) {
+        const int in = dims[k], out = dims[k + 1];
+        std::vector<float> hw((size_t)in * out), hb(out);
+        if (src_on_device) {
+          KR_HIP(hipMemcpy(hw.data(), W[k], hw.size() * sizeof(float), hipMemcpyDeviceToHost));
+          KR_HIP(hipMemcpy(hb.data(), b[k], hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        } else {
+          std::memcpy(hw.data(), W[k], hw.size() * sizeof(float));
+          std::memcpy(hb.data(), b[k], hb.size() * sizeof(float));
+        }
+        std::vector<float> w32((size_t)groups[k] * 64 * 4, 0.f), b32(64, 0.f);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = k == 2 ? (lane & 31) : lane;
+          const int k0 = k == 2 ? 32 * (lane >> 5) : 0;
+          if (row < out)
+            for (int g = 0; g < groups[k]; ++g)
+              for (int e = 0; e < 4; ++e) {
+                const int ui = k0 + 4 * g + e;
+                if (ui < in) w32[((size_t)g * 64 + lane) * 4 + e] = hw[(size_t)row * in + ui];
+              }
+          if (lane < out && (k < 2 || lane < 32)) b32[lane] = hb[lane];
+        }
+        void *pw, *pb;
+        KR_HIP(hipMalloc(&pw, w32.size() * sizeof(float))); h->mlp_allocs.push_back(pw);
+        KR_HIP(hipMalloc(&pb, b32.size() * sizeof(float))); h->mlp_allocs.push_back(pb);
+        KR_HIP(hipMemcpy(pw, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
+        KR_HIP(hipMemcpy(pb, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
+        mf.w32[k] = md.w32[k] = static_cast<float*>(pw);
+        mf.b32[k] = md.b32[k] = static_cast<float*>(pb);
+      }
+      mf.f32_ok = md.f32_ok = 1;
+    }
     mf.mfma_ok = md.mfma_ok = h->mfma_mlp ? 1 : 0;
     mf.jvp_ok = md.jvp_ok = (n_layers == 2 || dims[2] <= 64 * 3) ? 1 : 0;  // MJ_ACT_SLOTS - 1 chunks of the second hidden layer
   }

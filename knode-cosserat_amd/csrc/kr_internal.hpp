@@ -48,6 +48,11 @@ struct MlpDev {
   const float* bq[KR_MAX_LAYERS];
   int kgroups[KR_MAX_LAYERS];
   int jvp_ok;                  // shape served by mlp_jvp.hpp (second hidden layer <= 64 (MJ_ACT_SLOTS - 1) units)
+  // fp32 base chain of the same evaluator for in -> H1 <= 64 -> H2 <= 64 -> 25 (mlp_jvp_tile3f, v_mfma_f32_4x4x1_16B): lane l
+  // owns row l of the weight matrix, [k-group of 4][lane][4] f32; biases per row [64]
+  const float* w32[KR_MAX_LAYERS];
+  const float* b32[KR_MAX_LAYERS];
+  int f32_ok;
 };
 
 }  // namespace kr

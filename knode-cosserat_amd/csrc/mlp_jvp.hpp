@@ -106,8 +106,31 @@ __device__ unsigned long long mj_stamp_acc[16];
 #define MJ_STAMP(k) do {} while (0)
 #define MJ_STAMP_BEGIN() do {} while (0)
 #endif
+#ifdef MJ_STAMPS
+#define MJ_T3(k) do { __builtin_amdgcn_sched_barrier(0); mj3[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MJ_T3(k) do {} while (0)
+#endif
+#ifdef MJ_NOCVT  // timing experiment only: no f32 -> f64 conversion of the weight fragments (garbage values)
+typedef float mj_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double mj_nocvt(float a, float b) { mj_f2 v = {a, b}; return __builtin_bit_cast(double, v); }
+#define MJ_W(v, e) mj_nocvt((v)[(e) & 2], (v)[((e) & 2) + 1])
+#else
+#define MJ_W(v, e) ((double)(v)[e])
+#endif
+#ifndef MJ_VARIANT
+#define MJ_VARIANT 0
+#endif
 #define MJ_LDS __attribute__((address_space(3)))
 #define MJ_GLB __attribute__((address_space(1)))
+// Every LDS hand-off of the evaluator is between lanes of ONE wavefront (its scratch is the wavefront's own), and the LDS
+// unit serves a wavefront's instructions in order: a wavefront-scope fence (a compiler barrier) is all it takes.  The
+// workgroup-scope fence of mm_wave_sync also waits for every global load in flight (vmcnt(0)) - here the weight fragments
+// requested one layer ahead, i.e. a full L2 round trip at each of the evaluator's six synchronisation points.
+__device__ __forceinline__ void mj_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 typedef MJ_GLB const float* gfp;
 typedef MJ_GLB const f32x4* gf4p;
 typedef MJ_GLB const bf16x8* gbfp;
@@ -334,10 +357,10 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile(const fl
       f32x4 dh[4][4];
       zero_dh(dh);
       jvp_accumulate<4, 1>(dh, a1, bdx);
-      mm_wave_sync();
+      mj_wave_sync();
       bf16x8 b1[4][2];
       jvp_scale_pack(dh, actp, lane, b1, ptab);
-      mm_wave_sync();  // (actp is rewritten by the next chunk)
+      mj_wave_sync();  // (actp is rewritten by the next chunk)
       jvp_accumulate<MM_OUT_T, 2>(ojvp, ao, b1);
     }
   } else {
@@ -378,7 +401,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile(const fl
         MJ_STAMP(5);  // base output layer
       }
     }
-    mm_wave_sync();
+    mj_wave_sync();
     bf16x8 b1[4][2];
     {
       bf16x8 bdx[4][1];
@@ -410,7 +433,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile(const fl
   }
   // results: base outputs over the input rows, J dx rows over the dx rows (every lane has read its operands; the
   // sync orders the other lanes' reads before these writes)
-  mm_wave_sync();
+  mj_wave_sync();
 #pragma unroll
   for (int o2 = 0; o2 < MM_OUT_T; ++o2)
     if (16 * o2 + dunit < 25) xb[j4 * MJ_XB_LD + 16 * o2 + dunit] = (T)(obase[o2][0] + obase[o2][1]);
@@ -420,7 +443,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile(const fl
     for (int s = 0; s < 4; ++s)
       if (16 * o2 + 4 * q < MJ_DOUT_LD)  // units 16 o2 + 4 q .. + 3 as one 16-byte store (28 .. 31 do not exist)
         *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
-  mm_wave_sync();
+  mj_wave_sync();
 }
 
 // mlp_jvp_tile3: the evaluator for networks in -> H1 <= 64 -> H2 <= 64 -> 25 (every layer ONE chunk: BASELINE cfg3's
@@ -437,6 +460,10 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
                                                        const float* bq1, const float* bq2, const bf16x8* j0, const bf16x8* j1,
                                                        const bf16x8* j2, int kg1, int kg2, int ot0, int ot1, int jks1, int jks2,
                                                        int Lv, int ptabv, T* scratch_generic, int lane) {
+#ifdef MJ_STAMPS
+  unsigned long long mj3[12];
+#endif
+  MJ_T3(0);
   gf4p wq[3] = {(gf4p)uni64((unsigned long long)wq0), (gf4p)uni64((unsigned long long)wq1), (gf4p)uni64((unsigned long long)wq2)};
   gfp bq[3] = {(gfp)uni64((unsigned long long)bq0), (gfp)uni64((unsigned long long)bq1), (gfp)uni64((unsigned long long)bq2)};
   gbfp jq[3] = {(gbfp)uni64((unsigned long long)j0), (gbfp)uni64((unsigned long long)j1), (gbfp)uni64((unsigned long long)j2)};
@@ -483,7 +510,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
         if constexpr (decltype(batched)::value) bv = bvs[4 * g + e];
         else bv = chunk_operand(h, 4 * g + e);
 #pragma unroll
-        for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4((double)wo4[g][o2][e], bv, a4[2 * (g & 1) + o2]);
+        for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4(MJ_W(wo4[g][o2], e), bv, a4[2 * (g & 1) + o2]);
       }
     obase[0][0] = a4[0]; obase[1][0] = a4[1]; obase[0][1] = a4[2]; obase[1][1] = a4[3];
   };
@@ -511,73 +538,105 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
 #pragma unroll
     for (int o = 0; o < 4; ++o) { h1[o] = (double)bq[0][o * 64 + lane]; h2[o] = (double)bq[1][o * 64 + lane]; }
     base_load<4, 4>(w2, wq[1], 4, 0, 0, lane);
+    // Hand-off of a hidden layer to the next product through LDS (2.3 KB behind the dx rows, free until the results are
+    // stored): the activated values are written in the ORDER THE NEXT LAYER READS THEM - lane (k, *, j) needs input
+    // 4 ks + k of sample j for the 16 k-steps ks, sixteen consecutive doubles of row (j, k) - so the sixteen B operands
+    // of a layer are 8 ds_read_b128 behind ONE wait, where the in-register route took 32 ds_swizzle and a wait per
+    // k-step.  Rows are 18 doubles apart (bank spread).  The act' table goes through LDS anyway.
+    constexpr int HOP_LD = 18;
+    MJ_LDS double* hop = (MJ_LDS double*)(dreg + 64 * MJ_DX_LD * 2);
+    const int hop_w = ((lane & 3) * 4 + (lane >> 4)) * HOP_LD + ((lane >> 2) & 3);  // + 4 o: unit 16 o + 4 b + i = 4 (4 o + b) + i
+    const MJ_LDS double* hop_r = hop + ((lane & 3) * 4 + (lane >> 4)) * HOP_LD;
+    auto hand_off = [&](const double (&h)[4]) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) hop[hop_w + 4 * o] = h[o];
+    };
+    auto operands = [&](double (&bv)[16]) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const d2 v = *reinterpret_cast<const MJ_LDS d2*>(hop_r + 2 * e);
+        bv[2 * e] = v[0]; bv[2 * e + 1] = v[1];
+      }
+    };
     f32x4 dh[4][4];
     zero_dh(dh);
-    // layer 1: 2 k-groups of the base product, 8 JVP products behind each
+    MJ_T3(1);
+    // layer 1, base: 32 products
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) h1[o] = mfma4((double)w1[g][o][e], bin[4 * g + e], h1[o]);
-#pragma unroll
-      for (int o = 2 * g; o < 2 * g + 2; ++o)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
-    }
+        for (int o = 0; o < 4; ++o) h1[o] = mfma4(MJ_W(w1[g][o], e), bin[4 * g + e], h1[o]);
     __builtin_amdgcn_sched_barrier(0);
+    MJ_T3(2);
+    // layer 1, JVP (16 products) under the activation of the base chain: the matrix pipe works while the vector ALU does
     bf16x8 a2[2][4];
     jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
     chunk_activate<ACT>(h1, actp, lane);
-    mm_wave_sync();
+    hand_off(h1);
+    MJ_T3(3);
+    mj_wave_sync();
+    double bv[16];
+    operands(bv);
     bf16x8 b1[4][2];
     jvp_scale_pack(dh, actp, lane, b1, ptab);
-    // layer 2: 4 k-groups of the base product (operands: swizzled blocks of h1), 8 JVP products behind each
+    MJ_T3(4);
+    // layer 2, base: 64 products; the first k-step of the JVP (16 products) between them
     zero_dh(dh);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double bv = chunk_operand(h1, 4 * g + e);
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) h2[o] = mfma4((double)w2[g][o][e], bv, h2[o]);
-      }
+        for (int o = 0; o < 4; ++o) h2[o] = mfma4(MJ_W(w2[g][o], e), bv[4 * g + e], h2[o]);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0][g], b1[s][0], dh[g][s], 0, 0, 0);
-        dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][g], b1[s][1], dh[g][s], 0, 0, 0);
-      }
+      for (int s = 0; s < 4; ++s) dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0][g], b1[s][0], dh[g][s], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    MJ_T3(5);
+    // ... its second k-step (16 products) under the second activation
     f32x4 wo4[4][MM_OUT_T];
     bf16x8 ao[2][MM_OUT_T];
     base_load<MM_OUT_T, 4>(wo4, wq[2], kgs[2], 0, 0, lane);
     jvp_load<MM_OUT_T, 2>(ao, jq[2], jkss[2], 0, 0, lane);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][o], b1[s][1], dh[o][s], 0, 0, 0);
     chunk_activate<ACT>(h2, actp + 256, lane);
-    mm_wave_sync();
+    hand_off(h2);
+    MJ_T3(6);
+    mj_wave_sync();
+    operands(bv);
     bf16x8 b2[4][2];
     jvp_scale_pack(dh, actp + 256, lane, b2, ptab);
+    MJ_T3(7);
     // output layer: even / odd k-groups into separate partial sums; 4 JVP products behind each k-group
     {
       double a4[4] = {obase[0][0], obase[1][0], obase[0][1], obase[1][1]};
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const double bv = chunk_operand(h2, 4 * g + e);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4((double)wo4[g][o2][e], bv, a4[2 * (g & 1) + o2]);
-        }
+          for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4(MJ_W(wo4[g][o2], e), bv[4 * g + e], a4[2 * (g & 1) + o2]);
         const int ks = g >> 1, o2 = g & 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) ojvp[o2][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[ks][o2], b2[s][ks], ojvp[o2][s], 0, 0, 0);
       }
       obase[0][0] = a4[0]; obase[1][0] = a4[1]; obase[0][1] = a4[2]; obase[1][1] = a4[3];
     }
+    MJ_T3(8);
   }
   // results: base outputs over the input rows, J dx rows over the dx rows (every lane has read its operands; the
   // sync orders the other lanes' reads before these writes)
-  mm_wave_sync();
+  mj_wave_sync();
 #pragma unroll
   for (int o2 = 0; o2 < MM_OUT_T; ++o2)
     if (16 * o2 + dunit < 25) xb[j4 * MJ_XB_LD + 16 * o2 + dunit] = (T)(obase[o2][0] + obase[o2][1]);
@@ -587,9 +646,202 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
     for (int s = 0; s < 4; ++s)
       if (16 * o2 + 4 * q < MJ_DOUT_LD)  // units 16 o2 + 4 q .. + 3 as one 16-byte store (28 .. 31 do not exist)
         *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
-  mm_wave_sync();
+  mj_wave_sync();
+  MJ_T3(9);
+#ifdef MJ_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int k = 0; k < 9; ++k) mj_stamp_acc[k] += mj3[k + 1] - mj3[k];
+#endif
 }
 
+
+// mlp_jvp_tile3f: the same one-chunk three-layer evaluator for fp32 sweeps with the BASE CHAIN IN FP32 on
+// v_mfma_f32_4x4x1_16B_f32 (the fp64 chain above spends 128 v_cvt_f64_f32 - ~1.5 k cycles - on widening fp32 weights, and
+// an fp32 sweep cannot use the extra digits).  Layout (measured, tools/ubench_mfma3.hip): 16 blocks of D[4x4] += A[4x1] B[1x4];
+// lane l = (block b = l >> 2, index l & 3): A holds row i = l & 3, B column j = l & 3, D register r is D[b][r][j].  Used as
+// out^T[64 units x 4 samples]: block b carries units 4 b .. 4 b + 3, so lane l owns ROW l of the weight matrix (A operand
+// of k-step k = W[l][k]: fragments [k-group][lane][4], one 16-byte load per 4 k-steps), the B operand of k-step k is
+// input k of sample j, the same in every block (16-byte broadcast reads of row j of an LDS tile), and a lane ends up with
+// units 4 b .. 4 b + 3 of sample j - contiguous, so activations, act' and the hand-off to the next layer are ONE 16-byte
+// LDS write each.  8 cycles per product (4 independent accumulators: one per k mod 4), 124 products.  The output layer
+// (25 -> 32 rows) uses the upper 8 blocks for the second half of its k range; the halves meet through ds_bpermute.
+template <int ACT, int VAR = 0>
+__device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const float* w0, const float* w1p, const float* w2p,
+                                                                          const float* b0, const float* b1p, const float* b2p,
+                                                                          const bf16x8* j0, const bf16x8* j1, const bf16x8* j2,
+                                                                          int ptabv, float* scratch_generic, int lane) {
+  using T = float;
+#ifdef MJ_STAMPS
+  unsigned long long mj3[12];
+#endif
+  MJ_T3(0);
+  gf4p wf[3] = {(gf4p)uni64((unsigned long long)w0), (gf4p)uni64((unsigned long long)w1p), (gf4p)uni64((unsigned long long)w2p)};
+  gf4p bf[3] = {(gf4p)uni64((unsigned long long)b0), (gf4p)uni64((unsigned long long)b1p), (gf4p)uni64((unsigned long long)b2p)};
+  gbfp jq[3] = {(gbfp)uni64((unsigned long long)j0), (gbfp)uni64((unsigned long long)j1), (gbfp)uni64((unsigned long long)j2)};
+  const int ptab = uni(ptabv);
+  MJ_LDS unsigned char* sbase = (MJ_LDS unsigned char*)(unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned long long)(MJ_LDS unsigned char*)scratch_generic);
+  MJ_LDS T* xb = (MJ_LDS T*)sbase;
+  MJ_LDS float* actp = (MJ_LDS float*)(sbase + mj_xb_bytes<T>());
+  MJ_LDS unsigned char* dreg = sbase + mj_xb_bytes<T>() + MJ_ACTP_BYTES;
+  const MJ_LDS bf16x8* dx = (const MJ_LDS bf16x8*)dreg;
+  MJ_LDS float* dout = (MJ_LDS float*)dreg;
+  constexpr int HOP_LD = 68;  // floats per sample row of the hand-off tile (bank spread of the four rows)
+  MJ_LDS float* hop = (MJ_LDS float*)(dreg + 64 * MJ_DX_LD * 2);
+  const int q = lane >> 4, c = lane & 15, j4 = lane & 3, blk = lane >> 2;
+  auto mfma1 = [](float a, float b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0); };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 W1[7];
+#pragma unroll
+  for (int g = 0; g < 7; ++g) W1[g] = wf[0][g * 64 + lane];
+  bf16x8 a1[1][4];
+  jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
+  f32x4 acc[4] = {bf[0][blk], zero4, zero4, zero4};
+  f32x4 xin[16];
+#pragma unroll
+  for (int g = 0; g < 7; ++g) xin[g] = *reinterpret_cast<const MJ_LDS f32x4*>(xb + j4 * MJ_XB_LD + 4 * g);
+  bf16x8 bdx[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) bdx[s] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+  f32x4 W2[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) W2[g] = wf[1][g * 64 + lane];
+  const f32x4 bias2 = bf[1][blk];
+  f32x4 dh[4][4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dh[o][s] = zero4;
+  f32x4 ojvp[MM_OUT_T][4];
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ojvp[o2][s] = zero4;
+  // activation of the lane's four units, act' table and hand-off row: 16-byte writes
+  auto activate_hand_off = [&](f32x4& h, MJ_LDS float* tab) {
+    float v[4] = {h[0], h[1], h[2], h[3]};
+    activate_block<float, ACT, 4>(v);
+    f32x4 a = {v[0], v[1], v[2], v[3]};
+    f32x4 gr = {act_grad_from_value<ACT>(v[0]), act_grad_from_value<ACT>(v[1]), act_grad_from_value<ACT>(v[2]),
+                act_grad_from_value<ACT>(v[3])};
+    *reinterpret_cast<MJ_LDS f32x4*>(tab + j4 * 64 + 4 * blk) = gr;
+    *reinterpret_cast<MJ_LDS f32x4*>(hop + j4 * HOP_LD + 4 * blk) = a;
+    h = a;
+  };
+  MJ_T3(1);
+  // layer 1, base: 28 products
+#pragma unroll
+  for (int g = 0; g < 7; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = mfma1(W1[g][e], xin[g][e], acc[e]);
+#if MJ_VARIANT & 1
+    if (g < 4) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][g], bdx[s], dh[g][s], 0, 0, 0);
+    }
+#endif
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  MJ_T3(2);
+  // layer 1, JVP (16 products) under the activation
+  bf16x8 a2[2][4];
+  jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
+#if !(MJ_VARIANT & 1)
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
+#endif
+  f32x4 h = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  activate_hand_off(h, actp);
+  MJ_T3(3);
+  mj_wave_sync();
+#pragma unroll
+  for (int g = 0; g < 16; ++g) xin[g] = *reinterpret_cast<const MJ_LDS f32x4*>(hop + j4 * HOP_LD + 4 * g);
+  bf16x8 b1[4][2];
+  jvp_scale_pack(dh, actp, lane, b1, ptab);
+  MJ_T3(4);
+  // layer 2, base: 64 products; the first k-step of the JVP (16 products) between them
+  acc[0] = bias2; acc[1] = zero4; acc[2] = zero4; acc[3] = zero4;
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dh[o][s] = zero4;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = mfma1(W2[g][e], xin[g][e], acc[e]);
+    if ((g & 3) == 3) {
+      const int o = g >> 2;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0][o], b1[s][0], dh[o][s], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  MJ_T3(5);
+  // ... its second k-step (16 products) under the second activation
+  f32x4 Wo[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) Wo[g] = wf[2][g * 64 + lane];
+  bf16x8 ao[2][MM_OUT_T];
+  jvp_load<MM_OUT_T, 2>(ao, jq[2], 2, 0, 0, lane);
+  const f32x4 bias3 = bf[2][blk];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][o], b1[s][1], dh[o][s], 0, 0, 0);
+  h = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  activate_hand_off(h, actp + 256);
+  MJ_T3(6);
+  mj_wave_sync();
+  // output layer: lanes of the blocks 0..7 take k = 0..31, those of 8..15 k = 32..63 (rows 32..63 of the fragment array)
+  const int khalf = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) xin[g] = *reinterpret_cast<const MJ_LDS f32x4*>(hop + j4 * HOP_LD + 32 * khalf + 4 * g);
+  bf16x8 b2[4][2];
+  jvp_scale_pack(dh, actp + 256, lane, b2, ptab);
+  MJ_T3(7);
+  acc[0] = bias3; acc[1] = zero4; acc[2] = zero4; acc[3] = zero4;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = mfma1(Wo[g][e], xin[g][e], acc[e]);
+    if (g & 1) {
+      const int ks = g >> 2, o2 = (g >> 1) & 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ojvp[o2][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[ks][o2], b2[s][ks], ojvp[o2][s], 0, 0, 0);
+    }
+  }
+  h = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  MJ_T3(8);
+  // the two halves of the k range meet: lane l < 32 adds what lane l + 32 summed
+  {
+    // (component by component: written as a loop over h[r] with __builtin_bit_cast, hipcc 7.2 emitted ONE ds_bpermute and
+    //  added its result to all four components)
+    const int partner = (lane ^ 32) * 4;
+    const float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+    const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(h0)));
+    const float o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(h1)));
+    const float o2 = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(h2)));
+    const float o3 = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(h3)));
+    h = f32x4{h0 + o0, h1 + o1, h2 + o2, h3 + o3};
+  }
+  mj_wave_sync();
+  if (lane < 28) *reinterpret_cast<MJ_LDS f32x4*>(xb + j4 * MJ_XB_LD + 4 * blk) = h;  // units 4 blk .. 4 blk + 3 < 28 (25 used)
+#pragma unroll
+  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (16 * o2 + 4 * q < MJ_DOUT_LD)
+        *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
+  mj_wave_sync();
+  MJ_T3(9);
+#ifdef MJ_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int k = 0; k < 9; ++k) mj_stamp_acc[k] += mj3[k + 1] - mj3[k];
+#endif
+}
 
 // Per-lane wrapper.  iv / col: the lane's role (sub-interval of the wavefront 0..3, 0 = unperturbed); idle lanes pass
 // col = 0 and a copy of their interval's state.  zrow: the dx row a lane without a column zeroes (the rows no column
@@ -614,7 +866,7 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
       d[k] = v;
     }
   }
-  mm_wave_sync();
+  mj_wave_sync();
   // dx row of this lane; the lanes without a column (base and idle ones) zero the rows no column owns.  Written without
   // a branch on the lane's role: the wrapper sits in the middle of the register-starved sweep kernels, and spill code
   // inside divergent control flow there has produced wrong reloads (hipcc 7.2, fp64, kr_msw_impl.hpp with the MLP on).
@@ -646,11 +898,27 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
       dst[v] = p;
     }
   }
-  mm_wave_sync();
+  mj_wave_sync();
 #define MJ_TILE_ARGS                                                                                                        \
   M.wq[0], M.wq[1], M.wq[2], M.bq[0], M.bq[1], M.bq[2], reinterpret_cast<const bf16x8*>(M.jfrag[0]),                         \
       reinterpret_cast<const bf16x8*>(M.jfrag[1]), reinterpret_cast<const bf16x8*>(M.jfrag[2]), M.kgroups[1], M.kgroups[2],  \
       M.otiles[0], M.otiles[1], M.jksteps[1], M.jksteps[2], M.n_layers, ptab, scratch, lane
+  if constexpr (std::is_same<T, float>::value) {
+    if (M.f32_ok) {  // wave-uniform: one chunk per layer, fp32 base chain
+#define MJ_F_ARGS                                                                                                    \
+  M.w32[0], M.w32[1], M.w32[2], M.b32[0], M.b32[1], M.b32[2], reinterpret_cast<const bf16x8*>(M.jfrag[0]),             \
+      reinterpret_cast<const bf16x8*>(M.jfrag[1]), reinterpret_cast<const bf16x8*>(M.jfrag[2]), ptab, scratch, lane
+      switch (M.acts[0]) {
+        case KR_ACT_TANH: mlp_jvp_tile3f<KR_ACT_TANH, VAR>(MJ_F_ARGS); break;
+        case KR_ACT_SOFTPLUS: mlp_jvp_tile3f<KR_ACT_SOFTPLUS, VAR>(MJ_F_ARGS); break;
+        case KR_ACT_RELU: mlp_jvp_tile3f<KR_ACT_RELU, VAR>(MJ_F_ARGS); break;
+        case KR_ACT_ELU: mlp_jvp_tile3f<KR_ACT_ELU, VAR>(MJ_F_ARGS); break;
+        default: mlp_jvp_tile3f<KR_ACT_NONE, VAR>(MJ_F_ARGS); break;
+      }
+#undef MJ_F_ARGS
+      goto mj_evaluated;
+    }
+  }
   if (M.n_layers == 3 && M.otiles[1] == 4) {  // wave-uniform: one chunk per layer
     switch (M.acts[0]) {
       case KR_ACT_TANH: mlp_jvp_tile3<T, KR_ACT_TANH, VAR>(MJ_TILE_ARGS); break;
@@ -668,6 +936,7 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
     default: mlp_jvp_tile<T, KR_ACT_NONE, VAR>(MJ_TILE_ARGS); break;
   }
 #undef MJ_TILE_ARGS
+mj_evaluated:
   {
     const V* b = reinterpret_cast<const V*>(xb + iv * MJ_XB_LD);
     constexpr int NB = (25 + n - 1) / n;
@@ -691,7 +960,7 @@ __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM
       }
     }
   }
-  mm_wave_sync();
+  mj_wave_sync();
 }
 
 }  // namespace kr

@@ -290,8 +290,13 @@ __device__ __forceinline__ void fast_exp_block(const float (&xin)[N], float (&y)
 // fp32: torch's ELU uses expm1, so keep relative accuracy for small |x| with a short series.
 __device__ __forceinline__ double elu_neg(double x) { return fast_exp(x) - 1.0; }
 __device__ __forceinline__ float elu_neg(float x) {
-  const float series = x * (1.f + x * (0.5f + x * (0.16666667f + x * (0.041666668f + x * 0.0083333338f))));
-  return x > -0.25f ? series : __expf(x) - 1.f;
+  // both sides evaluated, one v_cndmask picks: as a conditional expression around __expf the compiler emitted a
+  // divergent branch per value (4 nested exec-mask regions per activation block, ~750 cycles for four values)
+  float series = x * (1.f + x * (0.5f + x * (0.16666667f + x * (0.041666668f + x * 0.0083333338f))));
+  float ex = __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.f;
+  // (opaque to the optimiser from here on: it turns a select between two "expensive" expressions back into a branch)
+  asm volatile("" : "+v"(series), "+v"(ex));
+  return x > -0.25f ? series : ex;
 }
 
 // activation functions of the residual MLP, cosserat_ode.py:92-106
@@ -338,8 +343,10 @@ __device__ __forceinline__ void activate_block(T (&x)[N]) {
 #pragma unroll
       for (int e = 0; e < N; ++e) x[e] = x[e] > T(0) ? x[e] : ex[e] - T(1);
     } else {
+      // max(x, 0) + elu_neg(min(x, 0)): no select for the compiler to turn into a divergent branch per value
+      // (elu_neg(0) is exactly 0, so positive inputs pass unchanged)
 #pragma unroll
-      for (int e = 0; e < N; ++e) x[e] = x[e] > T(0) ? x[e] : elu_neg(xm[e]);
+      for (int e = 0; e < N; ++e) x[e] = fmax(x[e], T(0)) + elu_neg(xm[e]);
     }
   } else if constexpr (ACT == KR_ACT_TANH) {
     T t2[N], ex[N];
