@@ -57,8 +57,12 @@ struct FChunk {
 };
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// Every MFMA kernel of this file runs ONE wavefront per workgroup (dim3(64)), so all LDS hand-offs are between lanes of
+// one wavefront, whose LDS instructions execute in order: a wavefront-scope fence (a compiler barrier) is enough.  The
+// workgroup-scope fence this used to be also drains every global load in flight (s_waitcnt vmcnt(0)) - the prefetched
+// weight fragments and row blocks - at each of the ~20 synchronisation points of a row block.
 __device__ __forceinline__ void fsync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -83,7 +87,9 @@ __global__ void pack_all_kernel(const PackArgs P) {
     const int in = P.in[k], out = P.out[k], ks = P.ks[k];
     const int n = P.tiles[k] * ks * 64;
     for (int i = tid; i < n; i += nth) {
-      const int lane = i & 63, s = (i >> 6) % ks, t = (i >> 6) / ks;
+      // element i = ((t * ks / 4 + s / 4) * 64 + lane) * 4 + s % 4: four consecutive k-steps of a lane are ONE 16-byte load
+      const int e = i & 3, lane = (i >> 2) & 63, g = (i >> 8) % (ks / 4), t = (i >> 8) / (ks / 4);
+      const int s = 4 * g + e;
       const int uo = 16 * t + (lane & 15), q = lane >> 4;
       const int ui = k == 0 ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
       P.wf[k][i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
@@ -98,7 +104,8 @@ __global__ void pack_all_kernel(const PackArgs P) {
       const int kst = P.kst[k];
       const int nt = P.in_tiles[k] * kst * 64;
       for (int i = tid; i < nt; i += nth) {
-        const int lane = i & 63, s = (i >> 6) % kst, ti = (i >> 6) / kst;
+        const int e = i & 3, lane = (i >> 2) & 63, g = (i >> 8) % (kst / 4), ti = (i >> 8) / (kst / 4);
+        const int s = 4 * g + e;
         const int ui = 16 * ti + (lane & 15), q = lane >> 4;
         const int uo = P.natural[k] ? 4 * s + q : 16 * (s / 4) + 4 * q + (s % 4);
         P.wt[k][i] = (uo < out && ui < in) ? W[(size_t)uo * in + ui] : 0.f;
@@ -112,21 +119,28 @@ __global__ void pack_all_kernel(const PackArgs P) {
 template <int NO, int KS, typename BFn>
 __device__ __forceinline__ void facc(f4 (&dst)[NO][FT], const float* __restrict__ w, int ksteps, int tile0, int ks0,
                                      int lane, BFn bsrc) {
-  float a[KS][NO];
+  // fragments [tile][k-group of 4][lane][4]: one 16-byte load per four k-steps (the single-dword loads of round 3 were
+  // 248 load instructions plus their address arithmetic per 32-row block); the next group is requested before the
+  // products of the current one are issued
+  static_assert(KS % 4 == 0, "k-steps come in groups of four");
+  constexpr int KG = KS / 4;
+  const f4* __restrict__ w4 = reinterpret_cast<const f4*>(w);
+  const int kg = ksteps >> 2, g0 = ks0 >> 2;
+  f4 a[KG][NO];
 #pragma unroll
-  for (int k = 0; k < (FPD < KS ? FPD : KS); ++k)
+  for (int o = 0; o < NO; ++o) a[0][o] = w4[((size_t)(tile0 + o) * kg + g0) * 64 + lane];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) a[k][o] = w[((size_t)(tile0 + o) * ksteps + ks0 + k) * 64 + lane];
+  for (int g = 0; g < KG; ++g) {
+    if (g + 1 < KG) {
 #pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    if (k + FPD < KS) {
-#pragma unroll
-      for (int o = 0; o < NO; ++o) a[k + FPD][o] = w[((size_t)(tile0 + o) * ksteps + ks0 + k + FPD) * 64 + lane];
+      for (int o = 0; o < NO; ++o) a[g + 1][o] = w4[((size_t)(tile0 + o) * kg + g0 + g + 1) * 64 + lane];
     }
 #pragma unroll
-    for (int o = 0; o < NO; ++o)
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int s = 0; s < FT; ++s) dst[o][s] = mfma4(a[k][o], bsrc(s, k), dst[o][s]);
+      for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int s = 0; s < FT; ++s) dst[o][s] = mfma4(a[g][o][e], bsrc(s, 4 * g + e), dst[o][s]);
     // keep the software pipeline as written: left alone, the scheduler hoists every fragment load of the chain to its
     // head and the kernel no longer fits two waves per SIMD
     __builtin_amdgcn_sched_barrier(0);

@@ -309,9 +309,9 @@ __device__ __forceinline__ T activate(int code, T x) {
     }
     case KR_ACT_SOFTPLUS: return log1p(fast_exp(-fabs(x))) + fmax(x, T(0));
     case KR_ACT_RELU: return fmax(x, T(0));
-    case KR_ACT_ELU: {  // branch-free: both sides are cheap, one v_cndmask picks
+    case KR_ACT_ELU: {  // max(x, 0) + (exp(min(x, 0)) - 1): nothing for the compiler to turn into a branch (elu_neg(0) == 0)
       const T e = elu_neg(fmin(x, T(0)));
-      return x > T(0) ? x : e;
+      return fmax(x, T(0)) + e;
     }
     default: return x;
   }
