@@ -196,6 +196,23 @@ int kr_mlp_eval_batch(kr_handle* h, int64_t Q, const void* x, void* out, int dty
 int kr_ode_batch(kr_handle* h, int64_t Q, const void* y, const void* yh, const void* zh, const void* tf,
                  void* dys, void* z, int use_nn, int dtype, void* stream);
 
+/* Derivatives of the PHYSICS of kr_ode_batch (use_nn = 0), what torch autograd propagates through
+ * CosseratRodTorch.ODE_parallel (cosserat_ode_torch.py:264-306) and through the op-by-op graph of
+ * CosseratRodTorch.getResidualEuler / ODE (:137-213, :325-367).  fp64 forward-mode differentiation on the
+ * device whatever `dtype` (the element type of the arrays).
+ *   kr_ode_vjp_batch: cotangents g_dys[Q][19], g_z[Q][6] -> J^T g with respect to y, yh, zh, tf
+ *     (g_y[Q][19], g_yh[Q][19], g_zh[Q][6], g_tf[Q][3]; any of the four may be NULL).
+ *   kr_ode_jacobian_batch: jac[Q][25][19] = d(dys, z) / dy of every row.
+ * cut != 0 reproduces the reference's ODE graph where it differs from the function it evaluates: the quadratic part of
+ * the rotation matrix (:159-162) and the quaternion-rate matrix (:185-189) are built with torch.tensor([...]), i.e.
+ * as leaves - h is then seen through 2 / (h . h) only, and h_s does not see u.  cut = 0: the complete derivative
+ * (ODE_parallel's graph). */
+int kr_ode_vjp_batch(kr_handle* h, int64_t Q, const void* y, const void* yh, const void* zh, const void* tf,
+                     const void* g_dys, const void* g_z, int cut, void* g_y, void* g_yh, void* g_zh, void* g_tf,
+                     int dtype, void* stream);
+int kr_ode_jacobian_batch(kr_handle* h, int64_t Q, const void* y, const void* yh, const void* zh, const void* tf,
+                          int cut, void* jac, int dtype, void* stream);
+
 /* ---- packed state helpers --------------------------------------------- */
 /* knode.py:58-66: straight rod along +z, unit quaternion, v = e3 */
 int kr_state_init_straight(kr_handle* h, int64_t B, void* state, int dtype, void* stream);

@@ -120,57 +120,11 @@ class _MlpFunction(torch.autograd.Function):
         return (None, dx, None, None, *grads)
 
 
-def _point_map_graph(rod, handle, y, yh, zh, tf, cut=True):
-    """Autograd graph of the physics of one grid point, y[Q, 19] -> (y_s[Q, 19], z[Q, 6]), in fp64 - used only for the
-    backward pass of ``getResidualEuler`` (the values themselves come from the HIP kernels).
-
-    ``cut=True`` reproduces the graph the reference's ``ODE`` builds (cosserat_ode_torch.py:137-213), which is not the
-    graph of the function it evaluates: the quadratic part of the rotation matrix (:159-162) and the quaternion-rate
-    matrix (:185-189) are assembled with ``torch.tensor([...])``, i.e. as new leaves.  Through R, h is seen only via
-    the factor 2 / (h . h); h_s sees h but not u.  ``cut=False`` differentiates everything."""
-    f64 = torch.float64
-    dev = y.device
-    d = handle.derived()
-    mat = lambda a: torch.tensor(np.array(a, dtype=np.float64).reshape(3, 3), dtype=f64, device=dev)
-    vec = lambda a: torch.tensor(np.array(a, dtype=np.float64).reshape(-1), dtype=f64, device=dev)
-    tn = lambda a: torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64), device=dev)
-    Ksei, Kbti, rhoJ = mat(d.Kse_plus_c0_Bse_inv), mat(d.Kbt_plus_c0_Bbt_inv), mat(d.rhoJ)
-    Kse_vstar, rhoAg = vec(d.Kse_vstar), vec(d.rhoAg)
-    Bse, Bbt, Cd = tn(rod.Bse).reshape(3, 3), tn(rod.Bbt).reshape(3, 3), tn(rod.C).reshape(3)
-    c0, rhoA = float(d.c0), float(d.rhoA)
-    hq, n, m, q, w = y[:, 3:7], y[:, 7:10], y[:, 10:13], y[:, 13:16], y[:, 16:19]
-    vh, uh = zh[:, 0:3], zh[:, 3:6]
-    a, b, c, e = (hq.detach() if cut else hq).unbind(dim=1)
-    quad = torch.stack([torch.stack([-c * c - e * e, b * c - e * a, b * e + c * a], dim=1),
-                        torch.stack([b * c + e * a, -b * b - e * e, c * e - b * a], dim=1),
-                        torch.stack([b * e - c * a, c * e + b * a, -b * b - c * c], dim=1)], dim=1)
-    R = torch.eye(3, dtype=f64, device=dev) + (2.0 / (hq * hq).sum(dim=1))[:, None, None] * quad
-    rot = lambda x: torch.einsum("qij,qj->qi", R, x)
-    rot_t = lambda x: torch.einsum("qji,qj->qi", R, x)
-    cross = lambda p_, q_: torch.linalg.cross(p_, q_, dim=1)
-    v = (rot_t(n) + Kse_vstar - vh @ Bse.t()) @ Ksei.t()
-    u = (rot_t(m) - uh @ Bbt.t()) @ Kbti.t()
-    z = torch.cat([v, u], dim=1)
-    qt, wt = c0 * q + yh[:, 13:16], c0 * w + yh[:, 16:19]
-    vt, ut = c0 * v + vh, c0 * u + uh
-    load = rhoAg - rot(Cd * q * q.abs()) + tf
-    ps = rot(v)
-    ns = rhoA * rot(cross(w, q) + qt) - load
-    ms = rot(cross(w, w @ rhoJ.t()) + wt @ rhoJ.t()) - cross(ps, n)
-    qs = vt - cross(u, q) + cross(w, v)
-    ws = ut - cross(u, w)
-    u0, u1, u2 = (u.detach() if cut else u).unbind(dim=1)
-    o = torch.zeros_like(u0)
-    omega = torch.stack([torch.stack([o, -u0, -u1, -u2], dim=1), torch.stack([u0, o, u2, -u1], dim=1),
-                         torch.stack([u1, -u2, o, u0], dim=1), torch.stack([u2, u1, -u0, o], dim=1)], dim=1)
-    hs = 0.5 * torch.einsum("qij,qj->qi", omega, hq)
-    return torch.cat([ps, hs, ns, ms, qs, ws], dim=1), z
-
-
 class _OdePhysicsFunction(torch.autograd.Function):
     """Physics part of ``ODE_parallel`` with gradients into its inputs (cosserat_ode_torch.py:264-306 lets autograd
-    flow there; no caller of the reference uses it).  Forward: ``kr_ode_batch``.  Backward: vector-Jacobian product of
-    the fp64 graph ``_point_map_graph`` (uncut - ODE_parallel builds R and the quaternion-rate matrix with torch.stack)."""
+    flow there; no caller of the reference uses it).  Forward: ``kr_ode_batch``.  Backward: ``kr_ode_vjp_batch`` - the
+    vector-Jacobian product of the point map by fp64 forward-mode differentiation on the device (uncut: ODE_parallel
+    builds R and the quaternion-rate matrix with torch.stack, so its graph is the complete derivative)."""
 
     @staticmethod
     def forward(ctx, rod, ys, yhs, zhs, tf):
@@ -183,13 +137,12 @@ class _OdePhysicsFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_dys, g_z):
-        rod = ctx.rod
-        leaves = [t.double().requires_grad_(True) for t in ctx.saved_tensors]
-        with torch.enable_grad():
-            ys_g, z_g = _point_map_graph(rod, rod._native(), *leaves, cut=False)
-            grads = torch.autograd.grad([ys_g, z_g], leaves, [g_dys.double(), g_z.double()], allow_unused=True)
-        out = [None if (g is None or not need) else g.float() for g, need in zip(grads, ctx.needs_input_grad[1:])]
-        return (None, *out)
+        h = ctx.rod._native()
+        ys, yhs, zhs, tf = ctx.saved_tensors
+        zero = lambda g, n: torch.zeros((ys.shape[0], n), dtype=torch.float32, device=ys.device) if g is None else g.float().contiguous()
+        need = tuple(bool(n) for n in ctx.needs_input_grad[1:])
+        grads = h.ode_vjp(ys, yhs, zhs, tf, zero(g_dys, 19), zero(g_z, 6), cut=False, need=need)
+        return (None, *grads)
 
 
 class _SweepFunction(torch.autograd.Function):
@@ -198,12 +151,12 @@ class _SweepFunction(torch.autograd.Function):
     Forward: the shooting-residual kernel (``kr_residual_batch``).  Backward: the discrete adjoint of the Euler sweep,
         lam_j = dL/dy_j = g_full[:19, j] + lam_{j+1} + J_j^T [ds lam_{j+1}; g_full[19:, j+1]],
     where J_j (25 x 19) is the Jacobian of one grid point's map y_j -> (y_s, z) including the network correction:
-    the physics part from ``_point_map_graph`` (all N - 1 points at once), the network's input Jacobian from forward
+    the physics part from ``kr_ode_jacobian_batch`` (all N - 1 points at once), the network's input Jacobian from forward
     differences of the device MLP (``kr_mlp_eval_batch``, fp64).  dL/dG = lam_0[7:13]; the parameter gradients are
     ``kr_mlp_backward`` on the rows x_j = [y_j, z_j before the correction, tendon force] with output gradients
     [ds lam_{j+1}; g_full[19:, j+1]].  Inputs other than G and the parameters (history, tensions) get no gradient.
     By default the adjoint follows the reference's GRAPH, which differs from the function it computes in two places
-    (see ``_point_map_graph``); ``rod.exact_sweep_gradient = True`` gives the true gradient instead."""
+    (include/knode_rod.h, kr_ode_vjp_batch: ``cut``); ``rod.exact_sweep_gradient = True`` gives the true gradient instead."""
 
     @staticmethod
     def forward(ctx, rod, G, *params):
@@ -237,18 +190,16 @@ class _SweepFunction(torch.autograd.Function):
         gf = g_full.to(f64)
         # ---- Jacobians of the N - 1 grid-point maps y_j -> (y_s, z), [Q, 25, 19] ----
         Q = N - 1
-        yq = y[:, :Q].t().to(f64).contiguous().requires_grad_(True)   # [Q, 19]
+        yq = y[:, :Q].t().to(f64).contiguous()   # [Q, 19]
         yhq = yh.float().to(dev)[:, :Q].t().to(f64).contiguous()
         zhq = zh.float().to(dev)[:, :Q].t().to(f64).contiguous()
         tdirs = torch.as_tensor(np.asarray(rod.tendon_dirs.detach().cpu() if torch.is_tensor(rod.tendon_dirs)
                                            else rod.tendon_dirs), dtype=f64, device=dev).reshape(4, 3)
         tf = (tens.to(dev).to(f64).reshape(1, 4) @ tdirs).expand(Q, 3).contiguous()
-        with torch.enable_grad():
-            ys_p, z_p = _point_map_graph(rod, h, yq, yhq, zhq, tf, cut=not getattr(rod, "exact_sweep_gradient", False))
-            Fp = torch.cat([ys_p, z_p], dim=1)
-            J = torch.stack([torch.autograd.grad(Fp[:, o].sum(), yq, retain_graph=True)[0] for o in range(25)], dim=1)
         yq = yq.detach()
-        z_p = z_p.detach()
+        # physics Jacobian of every grid point on the device (kr_ode_jacobian_batch, fp64 forward mode); z of the physics alone
+        J = h.ode_jacobian(yq, yhq, zhq, tf, cut=not getattr(rod, "exact_sweep_gradient", False))
+        _, z_p = h.ode_batch(yq, yhq, zhq, tf, use_nn=False)
         if use_nn:
             # correction added after the physics (cosserat_ode_torch.py:192-213): out = MLP([y, z, f_tendon]).  Its
             # input Jacobian from forward differences of the device MLP (fp64), chained with dz/dy of the physics
@@ -470,7 +421,7 @@ class CosseratRodTorch:
     def ODE(self, y, yh, zh, tendon_forces):
         """Single grid point, cosserat_ode_torch.py:137-214.  (Values as the reference; gradients into the inputs, when
         asked for, are those of ODE_parallel - the reference's single-point graph is cut at R(h) and at the
-        quaternion-rate matrix, which only ``getResidualEuler`` reproduces: see ``_point_map_graph``.)"""
+        quaternion-rate matrix, which only ``getResidualEuler`` reproduces: see kr_ode_vjp_batch (``cut``) in include/knode_rod.h.)"""
         dys, z = self.ODE_parallel(y.reshape(1, 19), yh.reshape(1, 19), zh.reshape(1, 6), tendon_forces.reshape(1, 3))
         return dys[0], z[0]
 

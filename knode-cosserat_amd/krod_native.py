@@ -70,6 +70,8 @@ _PROTOS = {
     "kr_mlp_eval_batch": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
     "kr_set_mlp": (_int, [_vp, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_vp), C.POINTER(_vp), _int, _vp]),
     "kr_ode_batch": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
+    "kr_ode_vjp_batch": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp]),
+    "kr_ode_jacobian_batch": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp]),
     "kr_state_init_straight": (_int, [_vp, _i64, _vp, _int, _vp]),
     "kr_state_pack": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
     "kr_state_unpack": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _vp]),
@@ -245,6 +247,25 @@ class Handle:
         check(self.lib.kr_ode_batch(self._h, Q, _ptr(y), _ptr(yh), _ptr(zh), _ptr(tf), _ptr(dys), _ptr(z),
                                     int(bool(use_nn)), dtype_code(y.dtype), _stream()))
         return dys, z
+
+    def ode_vjp(self, y, yh, zh, tf, g_dys, g_z, cut=False, need=(True, True, True, True)):
+        """J^T g of the physics of ``ode_batch`` with respect to (y, yh, zh, tf); entries not needed come back None."""
+        import torch
+        Q = y.shape[0]
+        outs = [torch.empty((Q, n), dtype=y.dtype, device=y.device) if w else None for n, w in zip((19, 19, 6, 3), need)]
+        check(self.lib.kr_ode_vjp_batch(self._h, Q, _ptr(y), _ptr(yh), _ptr(zh), _ptr(tf), _ptr(g_dys), _ptr(g_z),
+                                        int(bool(cut)), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]),
+                                        dtype_code(y.dtype), _stream()))
+        return outs
+
+    def ode_jacobian(self, y, yh, zh, tf, cut=False):
+        """[Q, 25, 19] Jacobian d(dys, z) / dy of the physics of ``ode_batch``."""
+        import torch
+        Q = y.shape[0]
+        jac = torch.empty((Q, 25, 19), dtype=y.dtype, device=y.device)
+        check(self.lib.kr_ode_jacobian_batch(self._h, Q, _ptr(y), _ptr(yh), _ptr(zh), _ptr(tf), int(bool(cut)),
+                                             _ptr(jac), dtype_code(y.dtype), _stream()))
+        return jac
 
     def new_state(self, B, dtype, n_slots=1):
         import torch

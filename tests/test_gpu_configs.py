@@ -155,18 +155,50 @@ def test_torch_full_sweep_autograd(torch_cuda, use_nn):
             assert rel_l2(prm.grad.cpu().numpy(), gg[f"dparam{k}"]) < 1e-3, k
     else:
         assert all(prm.grad is None for prm in rob.nn_models.parameters())
-    # the graph the backward pass differentiates evaluates to what the HIP ODE kernel computes
-    from cosserat_ode_torch import _point_map_graph
+    # the derivative kernels behind the backward passes (kr_ode_jacobian_batch, kr_ode_vjp_batch; fp64 forward mode on the
+    # device): the uncut Jacobian against central differences of the HIP ODE kernel itself, the VJP against J^T g and -
+    # for the history and tendon-force inputs - against central differences too
     h = rob._native()
     f64 = torch.float64
     yq = y.t().to(f64).contiguous()
     yhq = (rob.c1 * y + rob.c2 * yp).t().to(f64).contiguous()
     zhq = (rob.c1 * z + rob.c2 * zp).t().to(f64).contiguous()
     tf = (t(g["tres_tens"]).to(f64).reshape(1, 4) @ rob.tendon_dirs.to(f64).reshape(4, 3)).expand(10, 3).contiguous()
-    ys_k, z_k = h.ode_batch(yq, yhq, zhq, tf, use_nn=False)
-    ys_g, z_g = _point_map_graph(rob, h, yq, yhq, zhq, tf)
-    assert rel_l2(ys_g.cpu().numpy(), ys_k.cpu().numpy()) < 1e-12
-    assert rel_l2(z_g.cpu().numpy(), z_k.cpu().numpy()) < 1e-12
+    F = lambda a, b_, c_, d_: torch.cat(h.ode_batch(a.contiguous(), b_.contiguous(), c_.contiguous(), d_.contiguous(),
+                                                   use_nn=False), dim=1)
+    J = h.ode_jacobian(yq, yhq, zhq, tf, cut=False)
+    assert J.shape == (10, 25, 19)
+
+    def central(which, n):
+        cols = []
+        args = [yq, yhq, zhq, tf]
+        for i in range(n):
+            st = 1e-6 * torch.clamp(args[which][:, i].abs(), min=1.0)
+            ap = [a.clone() for a in args]
+            am = [a.clone() for a in args]
+            ap[which][:, i] += st
+            am[which][:, i] -= st
+            cols.append((F(*ap) - F(*am)) / (2 * st)[:, None])
+        return torch.stack(cols, dim=2)   # [Q, 25, n]
+
+    assert rel_l2(J.cpu().numpy(), central(0, 19).cpu().numpy()) < 1e-7
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    gd = torch.randn((10, 25), dtype=f64, device=DEV, generator=gen)
+    vy, vyh, vzh, vtf = h.ode_vjp(yq, yhq, zhq, tf, gd[:, :19].contiguous(), gd[:, 19:].contiguous(), cut=False)
+    assert rel_l2(vy.cpu().numpy(), torch.einsum("qod,qo->qd", J, gd).cpu().numpy()) < 1e-12
+    for got, which, n in ((vyh, 1, 19), (vzh, 2, 6), (vtf, 3, 3)):
+        want = torch.einsum("qod,qo->qd", central(which, n), gd)
+        assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 1e-7
+    # cut graph (what the reference's ODE builds): differs from the complete derivative exactly in the h columns
+    Jc = h.ode_jacobian(yq, yhq, zhq, tf, cut=True)
+    other = [c for c in range(19) if c not in (3, 4, 5, 6)]
+    assert torch.equal(Jc[:, :, other][:, [r for r in range(25) if r not in (3, 4, 5, 6)]],
+                       J[:, :, other][:, [r for r in range(25) if r not in (3, 4, 5, 6)]])
+    assert rel_l2(Jc[:, :, 3:7].cpu().numpy(), J[:, :, 3:7].cpu().numpy()) > 1e-3
+    # entries that need no gradient are not written
+    only = h.ode_vjp(yq, yhq, zhq, tf, gd[:, :19].contiguous(), gd[:, 19:].contiguous(), need=(False, False, True, False))
+    assert only[0] is None and only[1] is None and only[3] is None and torch.equal(only[2], vzh)
     # exact_sweep_gradient: the gradient of the function itself, against forward differences of the fp32 sweep (coarse)
     rob.exact_sweep_gradient = True
     G2 = t(g["tres_G"][1]).requires_grad_(True)
