@@ -440,3 +440,91 @@ def test_shipped_assembly_has_no_spill_in_whole_wave_brackets():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wwm_spill_scan.py")] + files,
                        capture_output=True, text=True)
     assert r.returncode == 0 and "0 spill(s)" in r.stdout, r.stdout[-2000:]
+
+
+# ---------------------------------------------------------------------------
+# the reference-side ctypes stub is checked against the header, so it cannot rot silently
+# ---------------------------------------------------------------------------
+def integration_stub_source():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = md[md.index("## B. Binding the C ABI directly"):]
+    code = sec[sec.index("```python") + len("```python"):]
+    return code[:code.index("```")]
+
+
+def header_prototypes():
+    """{name: number of parameters} of every function include/knode_rod.h declares, and the fields of struct kr_params."""
+    h = open(HEADER).read()
+    h_nc = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\s*\*|size_t)\s+(kr_\w+)\s*\(([^;{]*?)\)\s*;", h_nc, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    st = re.search(r"typedef struct kr_params\s*\{(.*?)\}\s*kr_params\s*;", h_nc, flags=re.S)
+    fields = []
+    for decl in st.group(1).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype = decl.split()[0]
+        for item in decl[len(ctype):].split(","):
+            mm = re.match(r"\s*(\w+)\s*(?:\[(\d+)\])?\s*$", item)
+            fields.append((mm.group(1), ctype, int(mm.group(2)) if mm.group(2) else 0))
+    return protos, fields
+
+
+def test_integration_stub_matches_the_header():
+    import ast
+    src = integration_stub_source()
+    tree = ast.parse(src)
+    protos, fields = header_prototypes()
+    assert len(protos) >= 40 and "kr_simulate_batch" in protos and "kr_ode_vjp_batch" in protos
+    # (1) every _lib.kr_* call passes as many positional arguments as the prototype has parameters
+    calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)
+             and isinstance(n.func.value, ast.Name) and n.func.value.id == "_lib" and n.func.attr.startswith("kr_")]
+    seen = set()
+    for c in calls:
+        name = c.func.attr
+        assert name in protos, f"INTEGRATION.md section B calls {name}, which include/knode_rod.h does not declare"
+        assert not c.keywords
+        assert len(c.args) == protos[name], (name, len(c.args), protos[name])
+        seen.add(name)
+    assert {"kr_default_params", "kr_create", "kr_state_init_straight", "kr_simulate_batch", "kr_state_unpack",
+            "kr_destroy"} <= seen
+    # (2) the Structure mirrors struct kr_params: same names, order, element types and array lengths
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "kr_params")
+    assign = next(n for n in cls.body if isinstance(n, ast.Assign) and n.targets[0].id == "_fields_")
+    got = []
+    for elt in assign.value.elts:
+        fname = elt.elts[0].value
+        t = elt.elts[1]
+        if isinstance(t, ast.BinOp):      # C.c_double * 9
+            got.append((fname, t.left.attr, t.right.value))
+        else:
+            got.append((fname, t.attr, 0))
+    ctype_of = {"double": "c_double", "int32_t": "c_int32", "int": "c_int32"}
+    want = [(n, ctype_of[t], k) for n, t, k in fields]
+    assert got == want, (got, want)
+
+
+@pytest.mark.gpu
+def test_integration_stub_runs():
+    """The stub itself, executed: its simulate_gpu() on a reference-shaped robot object reproduces the reference's cfg1 run."""
+    import types
+    import numpy as np
+    from conftest import rel_l2
+    import krod_native as kn
+    src = integration_stub_source().replace('C.CDLL("libknode_rod.so")', f'C.CDLL({kn.LIB_PATH!r})')
+    mod = types.ModuleType("_rod_backend")
+    exec(compile(src, "INTEGRATION.md:B", "exec"), mod.__dict__)
+    g = load_golden("sim_cfg1")
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot
+    robot = CosseratRod(use_fsolve=True)
+    setup_robot(robot)
+    robot.N = 20
+    robot.compute_intermediate_terms()
+    T = 40
+    out = mod.simulate_gpu(robot, g["ctl"][:T])
+    assert out.shape == (T + 1, 25, 20)
+    assert rel_l2(out[:T, :3, -1], g["tip"][:T]) < 1e-8
