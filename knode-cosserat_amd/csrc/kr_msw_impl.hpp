@@ -182,27 +182,34 @@ __device__ __forceinline__ RodHist<T> hist_lean(const RodConst<T>& P, const T (&
   return h;
 }
 
+// Barrier between the wavefronts of a rod for hand-offs that go through LDS only (everything inside a Newton iteration:
+// reductions, boundary blocks, updates).  __syncthreads() also waits for every global access in flight (s_waitcnt vmcnt(0)),
+// and on gfx950 vmcnt counts STORES too - after a storing sweep that is the whole state record stream on its way to HBM.
+__device__ __forceinline__ void msw_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // workgroup-wide reductions (W wavefronts, every one calls; scratch: W slots of T per call site)
 template <int W>
 __device__ __forceinline__ float msw_max(float v, float* red, int wave, int lane) {
   v = wave_max_nonneg(v);
   if (lane == 0) red[wave] = v;
-  __syncthreads();
+  msw_lds_barrier();
   float m = red[0];
 #pragma unroll
   for (int k = 1; k < W; ++k) m = fmaxf(m, red[k]);
-  __syncthreads();
+  msw_lds_barrier();
   return m;
 }
 template <int W>
 __device__ __forceinline__ double msw_sum(double v, double* red, int wave, int lane) {
   v = wave_sum_f64(v);
   if (lane == 0) red[wave] = v;
-  __syncthreads();
+  msw_lds_barrier();
   double s = red[0];
 #pragma unroll
   for (int k = 1; k < W; ++k) s += red[k];
-  __syncthreads();
+  msw_lds_barrier();
   return s;
 }
 
@@ -216,7 +223,7 @@ __device__ __forceinline__ void msw_sum_n(double (&v)[K], double* red, int wave,
 #pragma unroll
     for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
   }
-  __syncthreads();
+  msw_lds_barrier();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     double s = red[k];
@@ -224,7 +231,7 @@ __device__ __forceinline__ void msw_sum_n(double (&v)[K], double* red, int wave,
     for (int w = 1; w < W; ++w) s += red[w * K + k];
     v[k] = s;
   }
-  __syncthreads();
+  msw_lds_barrier();
 }
 template <int W, int K>
 __device__ __forceinline__ void msw_max_n(float (&v)[K], float* red, int wave, int lane) {
@@ -235,7 +242,7 @@ __device__ __forceinline__ void msw_max_n(float (&v)[K], float* red, int wave, i
 #pragma unroll
     for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
   }
-  __syncthreads();
+  msw_lds_barrier();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     float m = red[k];
@@ -243,7 +250,7 @@ __device__ __forceinline__ void msw_max_n(float (&v)[K], float* red, int wave, i
     for (int w = 1; w < W; ++w) m = fmaxf(m, red[w * K + k]);
     v[k] = m;
   }
-  __syncthreads();
+  msw_lds_barrier();
 }
 
 // two maxima at once (one pair of barriers)
@@ -252,11 +259,11 @@ __device__ __forceinline__ void msw_max2(float& a, float& b, float* red, int wav
   a = wave_max_nonneg(a);
   b = wave_max_nonneg(b);
   if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
-  __syncthreads();
+  msw_lds_barrier();
   a = red[0]; b = red[1];
 #pragma unroll
   for (int k = 1; k < W; ++k) { a = fmaxf(a, red[2 * k]); b = fmaxf(b, red[2 * k + 1]); }
-  __syncthreads();
+  msw_lds_barrier();
 }
 
 // Scaled maximum norm of this wavefront's part of the residual of a sweep (see ms_residual_norm): the interface
@@ -614,7 +621,7 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
 #ifdef KR_MS_STAMPS
     KR_STAMP_ADD(stamps.a1, ta);
 #endif
-    __syncthreads();
+    msw_lds_barrier();
 #ifdef KR_MS_STAMPS
     KR_STAMP_ADD(stamps.a2, ta);
 #endif
@@ -652,7 +659,7 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
           store_pair(L.Tm + (r - 7) * 8 + 2 * kp, n0, n1);
         }
       }
-      __syncthreads();
+      msw_lds_barrier();
     }
 #ifdef KR_MS_STAMPS
     KR_STAMP_ADD(stamps.a3, ta);
@@ -710,7 +717,7 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
         if (kp == 0) L.dY[(R.g0 + k + 1) * 19 + r] = part;
       }
     }
-    __syncthreads();
+    msw_lds_barrier();
     // ---- p rows: dY_{g+1}[p] = sum_{i<=g} (c_i[p] + A_i[p, :] dY_i[3:]) ------------------------------------------
     if (lane < 3 * R.K) {
       const int k = lane / 3, prow = lane - 3 * k;
@@ -734,7 +741,7 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
       }
       L.sp[g * 4 + prow] = s + s2;
     }
-    __syncthreads();
+    msw_lds_barrier();
     // ---- scaled update norm over this wavefront's unknowns, then over the rod -----------------------------------
     float dnf = 0.f;
     T updP = T(0), xsP = T(0);
@@ -998,7 +1005,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
         }
       }
       if (U.plane) dPl[U.pg * 3 + U.pprow] = U.updP;
-      __syncthreads();
+      msw_lds_barrier();
       if (U.dnf <= 3.0e38f) {   // (uniform over the workgroup)
         // "end states" of the second solve: Y_{g+1} + B_g dY_g[p] (tip rows of the last interval: F_tip + ...)
         RodState<T> ysub = y;
@@ -1075,7 +1082,7 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
         flush = true;
       }
     }
-    __syncthreads();
+    msw_lds_barrier();
 #ifdef KR_MS_STAMPS
     KR_STAMP_ADD(stamps.a4, ta);
     KR_STAMP_ADD(stamps.alg, tq);
