@@ -129,3 +129,34 @@ def test_iters_counts_both_phases(torch_cuda, monkeypatch, mode, W):
         assert h.get_option("last_waves_per_rod") == W
     assert int(status.max()) <= 1
     assert int(iters.min()) > 2, iters.tolist()   # 2 plain iterations + at least one damped one
+
+
+@pytest.mark.parametrize("act", ["tanh", "softplus", "relu", "elu"])
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-8), ("f32", 1e-5)])
+@pytest.mark.parametrize("mode,W", [("persistent", 1), ("multi", 1), ("persistent", 2)])
+def test_three_layer_networks_every_activation(torch_cuda, monkeypatch, act, dtype, tol, mode, W):
+    """28 -> 64 -> 48 -> 25 with each activation the reference's get_nn_output knows (cosserat_ode.py:92-106) through the
+    one-chunk evaluators of round 4 - fp64 base chain (mlp_jvp_tile3) in fp64 sweeps, fp32 base chain on
+    v_mfma_f32_4x4x1_16B (mlp_jvp_tile3f) in fp32 sweeps - against the oracle's tight Newton solve.  A second hidden layer
+    narrower than 64 exercises the zero padding of both fragment forms."""
+    import cosserat_oracle as orc
+    from knode import simulate_batch
+    set_mode_env(monkeypatch, mode, waves_per_rod=W)
+    N, T = 40, 6
+    mlp = orc.make_mlp([28, 64, 48, 25], act, seed=13)
+    mlp.weights = [w * 1.5 for w in mlp.weights]   # (a correction that matters; at 3 x the oracle's own Newton solve gives up)
+    r = make_robot(None, N)
+    inject(r, mlp)
+    ctl = np.stack([np.array(orc.calc_controls("sine", a, r.del_t, T)) for a in (0.8, 2.0)])
+    out = simulate_batch(r, ctl, dtype=dtype)
+    h = r._handle
+    assert h.get_option("last_sim_path") == (2 if mode == "persistent" else 1) and h.get_option("last_waves_per_rod") == W
+    assert np.all(out["status"] == 0)
+    D = orc.params_for(None, N).derived()
+    plain = orc.simulate(D, np.vstack([ctl[0], ctl[0][-1:]]), solver="newton")
+    for b in range(2):
+        want, info = orc.simulate(D, np.vstack([ctl[b], ctl[b][-1:]]), mlp=mlp, solver="newton", return_info=True)
+        assert np.all(info["ier"][:T] == 1)
+        assert rel_l2(out["traj"][b], want[: T + 1, :25]) < tol, (act, dtype, b)
+        if b == 0:
+            assert rel_l2(plain[: T + 1, :25], want[: T + 1, :25]) > 1e-4
