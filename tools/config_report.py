@@ -149,9 +149,12 @@ for N, kp in ((10, [3, 5, 7, 9]), (100, [33, 55, 77, 99])):
 
 print("cfg5  B=512, N=400, sine tensions; tolerance sweep on the reference fixture sim_n400 (single rod, 12 steps)")
 g = G("sim_n400"); r = robot(400)
-for dt in (torch.float64, torch.float32):
-    s, bad, path = timed_sim(r, 512, 60, dt, 1237, warm=30)
-    print(f"      {str(dt):14s} {s*1e6:7.1f} us/step -> {512/s/1e6:6.2f} M rod-steps/s (path {path}, unconverged {bad})")
+sys.path.insert(0, ROOT)
+import bench_legs as bl
+for dname in ("f64", "f32"):  # the leg bench.py reports as extra.cfg5 (one methodology, one number)
+    leg = bl.forward_leg(torch, 0, 512, 400, 60, 30, dname, 1237)
+    print(f"      {dname}  {leg['kernel_ms_per_step']*1e3:7.1f} us/step (HIP events; {leg['ms_per_step']*1e3:.1f} wall) -> {leg['value']/1e6:6.2f} M rod-steps/s "
+          f"({leg['kernel']}, unconverged {leg['unconverged']})")
 h = r._native()
 for dname, dt, tols in (("f64", torch.float64, (1e-6, 1e-8, 1e-10, 1e-12)), ("f32", torch.float32, (1e-3, 1e-4, 1e-5, 1e-6))):
     line = []

@@ -65,10 +65,18 @@ out["ode_batch"] = rec
 # cfg5 on the several-wavefront step kernel: kernel stats, HBM bytes per launch (FETCH_SIZE / WRITE_SIZE: units of 32 B on
 # gfx950 as in tools/summarise_profiles.py) against the algorithmic (75 N + 16) s B, SQ issue figures
 st = newest(os.path.join(G, f"{tag}_cfg5_stats", "**", "*kernel_stats.csv"))
-rec = {"what": "tools/cfg5_only.py: B=512, N=400, fp64, 30 + 60 steps, all steps of a call in one persistent launch (msw_sim_kernel, history records in LDS, newest states from HBM), two wavefronts per rod"}
+rec = {"what": "tools/cfg5_only.py = bench.py extra.cfg5: B=512, N=400, fp64, 30 untimed + 60 timed steps, all steps of a call in one persistent launch (msw_sim_kernel, history records in LDS, newest states from HBM), two wavefronts per rod"}
 if st: rec["kernel_stats"] = stats_rows(st, ("msw_sim_kernel", "msw_step_kernel", "ms_step_kernel"))
 log = os.path.join(G, f"{tag}_cfg5.log")
 if os.path.exists(log): rec["line"] = [l.strip() for l in open(log) if l.startswith("cfg5")][-1:]
+tr = newest(os.path.join(G, f"{tag}_cfg5_stats", "**", "*kernel_trace.csv"))
+if tr:  # the timed dispatch is the last one of the step kernel: 60 steps
+    rows = [r_ for r_ in csv.DictReader(open(tr)) if "msw_sim_kernel" in r_["Kernel_Name"]]
+    if rows:
+        last = max(rows, key=lambda r_: int(r_["Dispatch_Id"]))
+        dur = (int(last["End_Timestamp"]) - int(last["Start_Timestamp"])) * 1e-3
+        rec["timed_dispatch"] = {"kernel": last["Kernel_Name"][:80], "us": round(dur, 1), "steps": 60, "us_per_step": round(dur / 60, 2),
+                                 "dispatches_of_this_kernel_in_the_trace": len(rows)}
 for cname, d in (("FETCH_SIZE", f"{tag}_cfg5_fetch"), ("WRITE_SIZE", f"{tag}_cfg5_write")):
     c = counters(d, "msw_sim_kernel")
     if c:
