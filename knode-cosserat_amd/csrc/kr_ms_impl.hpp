@@ -1781,7 +1781,7 @@ static int launch_ms_nn(kr_handle* h, int scheme, const StepArgs<T>& a, hipStrea
 }
 // The one-launch-per-step kernels WITH the MLP live in their own translation units (kr_msn_f32.hip / kr_msn_f64.hip,
 // kr_msn_impl.hpp): they are the most register-starved kernels of the library, and hipcc 7.2 places ordinary VGPR
-// spills inside the whole-wave-mode brackets it opens to reach its SGPR-spill registers there (DESIGN.md section 4,
+// spills inside the whole-wave-mode brackets it opens to reach its SGPR-spill registers there (LABBOOK.md section 4,
 // tools/wwm_spill_scan.py).  Those units are compiled with SGPR spills going to memory instead of VGPR lanes, which
 // removes the brackets altogether.
 template <typename T>

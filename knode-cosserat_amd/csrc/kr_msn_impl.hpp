@@ -5,7 +5,7 @@
 // compiled with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 (Makefile): these kernels spill ~600 registers, and with SGPR
 // spills in VGPR lanes hipcc 7.2 opens whole-wave-mode brackets around their copies and schedules ordinary VGPR spills
 // INTO those brackets - a miscompile whenever a lane that was idle at the spill reads the slot later (found once in
-// msw_sim_kernel).  With SGPR spills in scratch memory no bracket exists; the build runs
+// msw_sim_kernel, DESIGN.md section 9 and LABBOOK.md section 4).  With SGPR spills in scratch memory no bracket exists; the build runs
 // tools/wwm_spill_scan.py over the assembly of every translation unit and fails on a hit.
 #pragma once
 #include "kr_ms_impl.hpp"

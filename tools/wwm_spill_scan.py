@@ -7,7 +7,7 @@ kernels: an ordinary VGPR spill / reload placed INSIDE a whole-wave-mode bracket
 that the compiler opened only to copy its SGPR-spill VGPRs.  Inside the bracket every lane is active, so a spill store
 writes the register's content of lanes that were inactive when the value was defined (garbage) over their copies in
 the slot; a later reload under a wider exec mask then sees that garbage.  (Found with rocgdb in msw_sim_kernel<double,
-true, 2, NN> - a zero offset register of the last wavefront's record store - see DESIGN.md.)
+true, 2, NN> - a zero offset register of the last wavefront's record store - see DESIGN.md section 9 and LABBOOK.md section 4.)
     python tools/wwm_spill_scan.py file.s [...]      exit code 1 if any hit
 """
 import re, sys
