@@ -95,6 +95,7 @@ struct kr_handle {
   int residual_test = 1;     // accept a storing sweep from its residual alone when the estimate is 256 x below the tolerance
   int overlap = 1;           // ... and overlap the verifying sweep of step t with the Jacobian sweep of step t + 1 (kr_mso_impl.hpp)
   int last_overlap = 0;      // the last kr_simulate_batch ran the overlapped kernel
+  int nn_lowp_first = 1;     // fp64, MLP on, persistent one-wavefront kernel: first sweep of a three-sweep step on the fp32 base chain
   void* resume_buf = nullptr;  // int32 per rod (SimArgs::resume)
   size_t resume_cap = 0;
   void* hist_ws = nullptr;     // history records [B][N][12] of the several-wavefront persistent kernel with the MLP on
@@ -208,6 +209,7 @@ struct SimArgs {
   int32_t* resume = nullptr;
   int residual_test = 1;  // option "residual_test"
   T* hist_ws = nullptr;   // kr_msw_impl.hpp, MLP on: [B][N][12] history records (global memory instead of LDS)
+  int nn_lowp = 1;        // option "nn_lowp_first" (MsSolveArgs::lowp_allowed)
 };
 
 // returns 1 when the persistent form does not apply

@@ -311,6 +311,12 @@ struct MsSolveArgs {
   T* lead12 = nullptr;
   bool quick_ok = true;  // option "residual_test": the residual test below may accept a storing sweep
   int prot = 0;          // persistent kernel with the MLP on: sweeps so far (which intervals the p-column lanes serve)
+  // fp64 with the MLP on (option "nn_lowp_first"): the FIRST sweep of a step may evaluate the network with the fp32 base
+  // chain when the step is going to need two Newton corrections anyway - its update only has to land within ~1e-7 of
+  // where the exact one would, the second correction starts from a distance of kappa d1^2 >> that.  Decided from the
+  // previous step of the same rod: its first update d1 left 4 kappa d1^2 above the tolerance.  Storing sweeps - the only
+  // ones acceptance is measured on - always run the fp64 chain.
+  bool lowp_allowed = false, lowp_first = false;
 };
 
 // Scaled maximum norm of the residual of a sweep - the interface jumps E_g - Y_{g+1} (19 rows each) and the tip
@@ -390,6 +396,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       const int gu = 6 - ga - gb;  // the interval nobody serves this sweep
       S.prot += 1;
       Cl.role.ptab = 1;
+      Cl.role.lowp = S.lowp_allowed && S.lowp_first && it == 0 && !storing && !flush;
       if (pl) {
         pg = pslot < 3 ? ga : gb;
         pc = pslot < 3 ? pslot : pslot - 3;
@@ -900,6 +907,11 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     }
     const T dn = (T)dnf;
     if (res_full > 0.f && finite) amp = dnf / res_full;
+    if constexpr (PCOL) {
+      // the next step's first sweep may run the network's base chain in fp32 iff this step's first update left the
+      // predicted error 4 kappa d1^2 above the tolerance (a second correction was needed whatever the first sweep's accuracy)
+      if (it == 1) S.lowp_first = finite && (kappa_in > T(0) ? T(4) * kappa_in * dn * dn > S.tol : dn > T(1e-3));
+    }
 #if defined(KR_MS_STAMPS) && defined(KR_QUICK_AUDIT)
     if (quick_est > 0.f && finite && dnf > 0.f) { stamps.qa = fmax(stamps.qa, (double)(dnf / quick_est)); stamps.qn += 1.0; }
 #endif
@@ -1617,6 +1629,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   S.tol = A.tol; S.tolA = A.tolA; S.fd_eps = A.fd_eps; S.maxit = A.maxit;
   S.kappa = Q.kappa;
   S.quick_ok = A.residual_test != 0;
+  S.lowp_allowed = NN && sizeof(T) == 8 && A.nn_lowp != 0 && M.f32_ok != 0;
+  S.lowp_first = true;  // (from the straight rod / a fresh call the first steps take three sweeps and more)
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];

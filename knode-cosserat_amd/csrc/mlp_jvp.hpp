@@ -848,11 +848,93 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
 // owns: every sample tile has 16, an interval 6 or 16 columns; -1 = lane layout 7 + 3 x 17 of kr_ms_impl.hpp).
 // xrow: the dx / J dx row of a lane with a column when it is not 16 iv + col - 1 (the p columns in sample tile 0).
 // x in, NN(x) (base lanes) or NN(x_base) + J dx (the others) out.
+// fp64 sweep, fp32 BASE CHAIN (mlp_jvp_tile3f) - for a sweep whose result only feeds a Newton update that is far from the
+// tolerance anyway (the first sweep of a step that will need two corrections: kr_ms_impl.hpp, ms_newton).  The evaluator
+// sees the wavefront's scratch in its fp32 layout; the fp64 base rows the dx rows are formed from (x - x_base must be taken
+// in fp64: the perturbations are 1e-7 relative) sit in the act' area, which the evaluator only writes later.
+template <int VAR = 0>
+__device__ __forceinline__ void mlp_jvp_eval_lowp(const MlpDev<double>& M, const double (&x)[MM_IN], double* scratch, int lane,
+                                                  int iv, int col, bool idle, int zrow, double (&out)[25], int xrow, int ptab) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  unsigned char* sb = reinterpret_cast<unsigned char*>(scratch);
+  float* xbf = reinterpret_cast<float*>(sb);
+  double* xb64 = reinterpret_cast<double*>(sb + mj_xb_bytes<float>());
+  unsigned char* dreg = sb + mj_xb_bytes<float>() + MJ_ACTP_BYTES;
+  const bool base = col == 0 && !idle;
+  if (base) {
+    d2* d = reinterpret_cast<d2*>(xb64 + iv * MJ_XB_LD);
+    f32x4* f = reinterpret_cast<f32x4*>(xbf + iv * MJ_XB_LD);
+#pragma unroll
+    for (int k = 0; k < MM_IN / 2; ++k) d[k] = d2{x[2 * k], x[2 * k + 1]};
+#pragma unroll
+    for (int k = 0; k < MM_IN / 4; ++k) f[k] = f32x4{(float)x[4 * k], (float)x[4 * k + 1], (float)x[4 * k + 2], (float)x[4 * k + 3]};
+  }
+  mj_wave_sync();
+  {
+    const bool has = col > 0;
+    const int row = has ? (xrow >= 0 ? xrow : 16 * iv + col - 1) : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
+    float d[MM_IN];
+    const d2* b = reinterpret_cast<const d2*>(xb64 + iv * MJ_XB_LD);
+#pragma unroll
+    for (int k = 0; k < MM_IN / 2; ++k) {
+      const d2 v = b[k];
+      d[2 * k] = has ? (float)(x[2 * k] - v[0]) : 0.f;
+      d[2 * k + 1] = has ? (float)(x[2 * k + 1] - v[1]) : 0.f;
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* dst = reinterpret_cast<u32x4*>(dreg + (size_t)row * (MJ_DX_LD * 2));
+    unsigned zpad;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zpad));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      u32x4 p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 8 * v + 2 * e;
+        p[e] = k + 1 < MM_IN ? pack_bf2(d[k < MM_IN ? k : 0], d[k + 1 < MM_IN ? k + 1 : 0]) : zpad;
+      }
+      dst[v] = p;
+    }
+  }
+  mj_wave_sync();
+#define MJ_F_ARGS                                                                                                    \
+  M.w32[0], M.w32[1], M.w32[2], M.b32[0], M.b32[1], M.b32[2], reinterpret_cast<const bf16x8*>(M.jfrag[0]),             \
+      reinterpret_cast<const bf16x8*>(M.jfrag[1]), reinterpret_cast<const bf16x8*>(M.jfrag[2]), ptab, xbf, lane
+  switch (M.acts[0]) {
+    case KR_ACT_TANH: mlp_jvp_tile3f<KR_ACT_TANH, VAR>(MJ_F_ARGS); break;
+    case KR_ACT_SOFTPLUS: mlp_jvp_tile3f<KR_ACT_SOFTPLUS, VAR>(MJ_F_ARGS); break;
+    case KR_ACT_RELU: mlp_jvp_tile3f<KR_ACT_RELU, VAR>(MJ_F_ARGS); break;
+    case KR_ACT_ELU: mlp_jvp_tile3f<KR_ACT_ELU, VAR>(MJ_F_ARGS); break;
+    default: mlp_jvp_tile3f<KR_ACT_NONE, VAR>(MJ_F_ARGS); break;
+  }
+#undef MJ_F_ARGS
+  {
+    const f32x4* b = reinterpret_cast<const f32x4*>(xbf + iv * MJ_XB_LD);
+    const int row = col > 0 ? (xrow >= 0 ? xrow : 16 * iv + col - 1) : (zrow >= 0 ? zrow : 6 + (idle ? 4 + (lane - 58) : iv));
+    const bool has = col > 0;
+    const f32x4* dr = reinterpret_cast<const f32x4*>(dreg + (size_t)row * (MJ_DOUT_LD * 4));
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const f32x4 v = b[k], w = dr[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * k + e < 25) out[4 * k + e] = (double)v[e] + (has ? (double)w[e] : 0.0);  // (the sum in fp64: J dx is ~1e-7 of the base value)
+    }
+  }
+  mj_wave_sync();
+}
+
 template <typename T, int VAR = 0>
 __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
-                                             bool idle, int zrow, T (&out)[25], int xrow = -1, int ptab = 0) {
+                                             bool idle, int zrow, T (&out)[25], int xrow = -1, int ptab = 0, bool lowp = false) {
   using V = typename MjVec<T>::type;
   constexpr int n = MjVec<T>::n;
+  if constexpr (std::is_same<T, double>::value) {
+    if (__builtin_amdgcn_readfirstlane((int)lowp) && M.f32_ok) {  // wave-uniform
+      mlp_jvp_eval_lowp<VAR>(M, x, scratch, lane, iv, col, idle, zrow, out, xrow, ptab);
+      return;
+    }
+  }
   T* xb = scratch;
   unsigned char* dreg = reinterpret_cast<unsigned char*>(scratch) + mj_xb_bytes<T>() + MJ_ACTP_BYTES;
   const bool base = col == 0 && !idle;
