@@ -350,6 +350,29 @@ int kr_adam_plateau_step(kr_handle* h, int64_t n, float* params, float* grads, f
                          double weight_decay, int64_t step, int64_t n_zero, int64_t loss_index, double factor,
                          int patience, double threshold, double min_lr, float* loss_log, void* stream);
 
+/* ONE EPOCH of the one-step-ahead training loop on one rank - the body of physics_train.py:283-304 / :388-401 for the
+ * epoch's whole data set: prediction of every scored row from the MLP, the four-term loss, loss.backward() restricted to
+ * the MLP, optimizer.step() (Adam), scheduler.step(total_loss) (ReduceLROnPlateau), the weight clamp - as 3 (two-layer
+ * network) or 4 (three-layer) kernel launches and no host round trip.  It is kr_mlp_forward_loss + kr_mlp_backward +
+ * kr_adam_plateau_step with the glue between them removed: the loss partials and the per-workgroup gradient slabs are
+ * added up inside the optimizer launch (fixed order, no atomics: an epoch is reproducible bit for bit), and that launch
+ * also writes every updated parameter into the MFMA fragment buffers of `ws`, so the next epoch starts without a packing
+ * launch.
+ *   params, grads, exp_avg, exp_avg_sq, lower: flat fp32 vectors in nn.Linear order W1 [out][in], b1, W2, b2, (W3, b3);
+ *   grads has ONE trailing slot (the loss) and must be zero on entry of phase 0 / 1 (every update leaves it so);
+ *   x [S*K][in_pad], base, target_rows [S*K][25], dout [S*K][32] (scratch), ws (kr_mlp_ws_bytes), sched, the Adam and
+ *   plateau arguments, step, loss_log: as in kr_mlp_forward_loss and kr_adam_plateau_step.
+ *   phase 0: the whole epoch.  phase 1: everything up to the update - grads then holds the summed gradients and the loss,
+ *   ready for a data-parallel all-reduce - and phase 2: the update from grads as they stand (after the all-reduce).
+ *   repack != 0: the caller changed `params` since the last call (a loaded checkpoint): fragments are packed afresh.
+ *   They are also packed whenever ws, params or the network differ from the handle's previous call.
+ * KR_E_UNSUPPORTED for networks the fused training kernels do not serve (use the three separate calls). */
+int kr_train_epoch(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* dims, const int32_t* acts, float* params,
+                   float* grads, float* exp_avg, float* exp_avg_sq, const float* lower, double* sched, const float* x,
+                   int in_pad, const float* base, const float* target_rows, double denom, float* dout, void* ws,
+                   double beta1, double beta2, double eps, double weight_decay, int64_t step, double factor,
+                   int patience, double threshold, double min_lr, float* loss_log, int phase, int repack, void* stream);
+
 /* The same loss against pre-gathered targets: the states a training set is scored against never
  * change between epochs, so kr_gather_targets extracts rows[S*K][25] once (y rows at column idx[k],
  * z rows at idx[k]-1) and kr_loss_rows_fwd_bwd reads them contiguously.  pred may be NULL. */

@@ -88,6 +88,11 @@ struct kr_handle {
   int waves_per_rod = 0;     // per-step launches: wavefronts that share a rod (kr_msw_impl.hpp): 0 auto, 1, 2 or 4
   int last_waves_per_rod = 1;  // what the last step launch used
   void* loss_scratch = nullptr;  // per-workgroup loss partials of the fused forward + loss kernel
+  // kr_train_epoch: the MFMA weight fragments in `frag_ws` mirror the flat parameter vector `frag_params` (the epoch's tail
+  // kernel writes every updated parameter to both); another workspace, vector or network means packing afresh
+  const void* frag_ws = nullptr;
+  const void* frag_params = nullptr;
+  uint64_t frag_net = 0;
   void* dbg = nullptr;       // diagnostic cycle-counter buffer (kr_debug_buffer)
   int fused_mlp = 1;         // training: fused MFMA forward/backward kernels (kr_mlp_fused.hip) when the shape allows
   int mfma_mlp = 1;          // evaluate the in-sweep MLP on the matrix cores when its shape allows
@@ -250,11 +255,43 @@ struct FusedLoss {
   float ds, inv_denom;
   int K;
 };
+// do_pack = false: the fragments in ws are current (kr_train_epoch keeps them so); n_partials != nullptr: the loss
+// partials stay in fl->scratch, *n_partials of them, for the caller's next kernel
 int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
                       const float* const* b, const float* x, float* out, void* ws, hipStream_t s,
-                      const FusedLoss* fl = nullptr);
+                      const FusedLoss* fl = nullptr, bool do_pack = true, int* n_partials = nullptr);
+// leave != nullptr: no reduction launch - the slabs of partial gradients are described there (dW, db unused)
+struct FusedSlabs {
+  const float* slab;
+  int nslab, P, nparams;
+  int poff[6];
+};
 int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
-                       const float* x, const float* dout, void* ws, float* const* dW, float* const* db, hipStream_t s);
+                       const float* x, const float* dout, void* ws, float* const* dW, float* const* db, hipStream_t s,
+                       FusedSlabs* leave = nullptr);
+// kr_train_epoch: flat parameter / gradient / moment vectors in nn.Linear order (W1, b1, W2, b2, ...), g with one
+// trailing loss slot
+struct FusedEpoch {
+  int64_t Q;
+  int K, n_layers;
+  const int32_t* dims;
+  const int32_t* acts;
+  float *p, *g, *m, *v;
+  const float* lower;
+  double* sched;
+  const float *x, *base, *target_rows;
+  float* dout;
+  void* ws;
+  void* loss_scratch;
+  float ds, inv_denom;
+  double beta1, beta2, eps, weight_decay, factor, threshold, min_lr;
+  int patience;
+  int64_t step;
+  float* loss_log;
+  int phase;
+  bool pack;
+};
+int fused_train_epoch(const FusedEpoch& E, hipStream_t s);
 
 // kr_ode.hip
 template <typename T>

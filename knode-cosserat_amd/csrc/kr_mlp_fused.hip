@@ -623,13 +623,65 @@ __device__ __forceinline__ void wgrad_T(f4 (&acc)[NO][NI], const float* ta, cons
 //   pass A   X -> A1 -> A2;  dW3 += dOUT^T A2;  dZ2 = (W3^T dOUT) * act'(Z2);  dW2 += dZ2^T A1;  db2, db3;
 //            dZ2 leaves as a raw register dump [block][tile][sample tile][lane] x 16 bytes (coalesced both ways)
 //   pass B   X -> A1 (layer 1 again: 10 % more matrix work);  dZ1 = (W2^T dZ2) * act'(Z1);  dW1 += dZ1^T X;  db1
+// The two passes run WPB wavefronts per workgroup.  The wavefronts of a workgroup work on their own row blocks with their
+// own tiles and meet only once, after the last block: their weight-gradient accumulators are added up through the LDS
+// (two rounds of a tree) and leave the workgroup as ONE slab - a quarter of the slab bytes written here and read by the
+// reduction (2048 slabs x 30 KB = 63 MB each way per epoch before).
+constexpr int WPB = 4;
+constexpr int B3A_LDS = (32 + 64 + 64) * TP;  // floats per wavefront: dOUT^T, A1, A2 -> dZ2
+constexpr int B3B_LDS = (32 + 64) * TP;       // X^T, A1 -> dZ1
+extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+
+// acc (NA x NI and NB x NI accumulator tiles, two per-lane scalars) <- sum over the WPB wavefronts of the workgroup; the
+// result is valid in wavefront 0.  R: the workgroup's LDS (free once every wavefront is past its last row block).
+template <int NA, int NB, int NI, int NI2>
+__device__ __forceinline__ void wg_tree_sum(f4 (&a)[NA][NI], f4 (&b)[NB][NI2], float& s0, float& s1, float* lds, int w,
+                                            int lane) {
+  static_assert(WPB == 4, "two rounds");
+  constexpr int NF = NA * NI + NB * NI2 + 1;
+  f4* R = reinterpret_cast<f4*>(lds);
+  auto put = [&](f4* dst) {
+#pragma unroll
+    for (int o = 0; o < NA; ++o)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) dst[(o * NI + i) * 64 + lane] = a[o][i];
+#pragma unroll
+    for (int o = 0; o < NB; ++o)
+#pragma unroll
+      for (int i = 0; i < NI2; ++i) dst[(NA * NI + o * NI2 + i) * 64 + lane] = b[o][i];
+    dst[(NF - 1) * 64 + lane] = f4{s0, s1, 0.f, 0.f};
+  };
+  auto add = [&](const f4* src) {
+#pragma unroll
+    for (int o = 0; o < NA; ++o)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[o][i] = a[o][i] + src[(o * NI + i) * 64 + lane];
+#pragma unroll
+    for (int o = 0; o < NB; ++o)
+#pragma unroll
+      for (int i = 0; i < NI2; ++i) b[o][i] = b[o][i] + src[(NA * NI + o * NI2 + i) * 64 + lane];
+    const f4 t = src[(NF - 1) * 64 + lane];
+    s0 += t[0];
+    s1 += t[1];
+  };
+  __syncthreads();
+  if (w & 1) put(R + (w >> 1) * NF * 64);
+  __syncthreads();
+  if (!(w & 1)) add(R + (w >> 1) * NF * 64);
+  __syncthreads();
+  if (w == 2) put(R);
+  __syncthreads();
+  if (w == 0) add(R);
+}
+
 template <int ACT>
-__global__ __launch_bounds__(64, 2) void mlp_bwd3a_kernel(const FusedArgs A) {
-  __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // dOUT^T
-  __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1
-  __shared__ __attribute__((aligned(16))) float tv[64 * TP];  // A2 -> dZ2
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3a_kernel(const FusedArgs A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const ts = wg_lds + wv * B3A_LDS;  // dOUT^T
+  float* const tu = ts + 32 * TP;           // A1
+  float* const tv = tu + 64 * TP;           // A2 -> dZ2
   const int64_t nblk = (A.Q + FR - 1) / FR;
+  const int64_t wave0 = (int64_t)blockIdx.x * WPB + wv, nwaves = (int64_t)gridDim.x * WPB;
   f4 aW2[4][4], aW3[2][4];
 #pragma unroll
   for (int o = 0; o < 4; ++o)
@@ -640,7 +692,7 @@ __global__ __launch_bounds__(64, 2) void mlp_bwd3a_kernel(const FusedArgs A) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) aW3[o][i] = f4{0.f, 0.f, 0.f, 0.f};
   float pb2 = 0.f, pbo = 0.f;  // bias gradients of unit `lane`: row sums of the dZ2 / dOUT^T tiles
-  for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+  for (int64_t rb = wave0; rb < nblk; rb += nwaves) {
     stage_rows_T(A.dout, rb * FR, A.Q, ts, lane);
     {
       FChunk h;
@@ -668,6 +720,8 @@ __global__ __launch_bounds__(64, 2) void mlp_bwd3a_kernel(const FusedArgs A) {
     wgrad_T<4, 4>(aW2, tv, tu, lane);  // dW2 += dZ2^T A1
     fsync();
   }
+  wg_tree_sum(aW2, aW3, pb2, pbo, wg_lds, wv, lane);
+  if (wv != 0) return;
   float* slab = A.slab + (size_t)blockIdx.x * A.P;
   wgrad_flush<2, 4>(aW3, slab + A.poff[4], A.nout, A.h2, 0, 0, lane);
   wgrad_flush<4, 4>(aW2, slab + A.poff[2], A.h2, A.h1, 0, 0, lane);
@@ -676,18 +730,19 @@ __global__ __launch_bounds__(64, 2) void mlp_bwd3a_kernel(const FusedArgs A) {
 }
 
 template <int ACT>
-__global__ __launch_bounds__(64, 2) void mlp_bwd3b_kernel(const FusedArgs A) {
-  __shared__ __attribute__((aligned(16))) float ts[32 * TP];  // X^T
-  __shared__ __attribute__((aligned(16))) float tu[64 * TP];  // A1 -> dZ1
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3b_kernel(const FusedArgs A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const ts = wg_lds + wv * B3B_LDS;  // X^T
+  float* const tu = ts + 32 * TP;           // A1 -> dZ1
   const int64_t nblk = (A.Q + FR - 1) / FR;
+  const int64_t wave0 = (int64_t)blockIdx.x * WPB + wv, nwaves = (int64_t)gridDim.x * WPB;
   f4 aW1[4][2];
 #pragma unroll
   for (int o = 0; o < 4; ++o)
 #pragma unroll
     for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
   float pb1 = 0.f;
-  for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+  for (int64_t rb = wave0; rb < nblk; rb += nwaves) {
     stage_rows_T(A.x, rb * FR, A.Q, ts, lane);
     FChunk d2;
     chunk_undump(d2, A.dz2, rb, lane);
@@ -708,6 +763,12 @@ __global__ __launch_bounds__(64, 2) void mlp_bwd3b_kernel(const FusedArgs A) {
     wgrad_T<4, 2>(aW1, tu, ts, lane);  // dW1 += dZ1^T X
     fsync();
   }
+  {
+    f4 none[1][1] = {{f4{0.f, 0.f, 0.f, 0.f}}};
+    float unused = 0.f;
+    wg_tree_sum(aW1, none, pb1, unused, wg_lds, wv, lane);
+  }
+  if (wv != 0) return;
   float* slab = A.slab + (size_t)blockIdx.x * A.P;
   wgrad_flush<4, 2>(aW1, slab + A.poff[0], A.h1, A.in, 0, 0, lane);
   if (lane < A.h1) slab[A.poff[1] + lane] = pb1;
@@ -801,6 +862,158 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const FusedArgs A) {
   atomicAdd(&dst[i - A.poff[seg]], sum);
 }
 
+// ---- tail of an epoch: slab sum + loss sum + Adam + clamp + plateau schedule + fragment update, ONE launch ----------
+// (physics_train.py:289-304: optimizer.step(), scheduler.step(total_loss), the weight clamp.)  A workgroup owns 64
+// consecutive parameters and does everything for them - no workgroup waits for another, no atomics, and the order of
+// every sum is fixed, so an epoch is reproducible bit for bit:
+//   g[i] += sum over the slabs (16 slab groups x 16-byte loads, added up through the LDS);
+//   the workgroup that holds the loss slot g[nparams] adds the forward kernel's per-workgroup loss partials to it;
+//   update != 0: torch.optim.Adam + clamp on p[i] (adam_plateau_kernel's arithmetic), g[i] = 0, and the new value goes
+//   straight to its places in the MFMA fragment buffers the next epoch's kernels read (pack_all_kernel's layout: one
+//   forward fragment slot, one transposed slot for layers > 0, sixteen bias slots) - the separate packing launch of
+//   every epoch is gone; the thread of the loss slot steps ReduceLROnPlateau.
+// update == 0 stops after the sums: the gradients and the loss are complete in g for a data-parallel all-reduce, and a
+// second launch with nslab = nlpart = 0 does the rest.
+struct TailArgs {
+  const float* slab;
+  int nslab, P, nparams;
+  float *p, *g, *m, *v;
+  const float* lower;
+  double* sched;
+  int parity;
+  float inv_bc1, b1, b2, inv_sqrt_bc2, eps, wd;
+  double factor, threshold, min_lr;
+  int patience;
+  float* loss_log;
+  const float* lpart;
+  int nlpart;
+  int update;
+  int L;
+  int poff[7];
+  int in[3], out[3], ks[3], kst[3], natural[3];
+  float* wf[3];
+  float* bf[3];
+  float* wt[3];
+};
+constexpr int TAIL_T = 1024, TAIL_G = TAIL_T / 16;  // threads of a workgroup, slab groups (16 lanes x 16 bytes = 64 parameters each)
+__global__ __launch_bounds__(TAIL_T) void train_tail_kernel(const TailArgs T) {
+  __shared__ __attribute__((aligned(16))) float red[TAIL_G][64];
+  __shared__ float lred[TAIL_T];
+  const int tid = threadIdx.x, c0 = blockIdx.x * 64;
+  {
+    const int l16 = tid & 15, sg = tid >> 4;
+    f4 a0 = f4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (c0 + 4 * l16 < T.P) {
+      const float* src = T.slab + c0 + 4 * l16;
+      int w = sg;
+      for (; w + 3 * TAIL_G < T.nslab; w += 4 * TAIL_G) {
+        const f4 v0 = *reinterpret_cast<const f4*>(src + (size_t)w * T.P);
+        const f4 v1 = *reinterpret_cast<const f4*>(src + (size_t)(w + TAIL_G) * T.P);
+        const f4 v2 = *reinterpret_cast<const f4*>(src + (size_t)(w + 2 * TAIL_G) * T.P);
+        const f4 v3 = *reinterpret_cast<const f4*>(src + (size_t)(w + 3 * TAIL_G) * T.P);
+        a0 = a0 + v0; a1 = a1 + v1; a2 = a2 + v2; a3 = a3 + v3;
+      }
+      for (; w < T.nslab; w += TAIL_G) a0 = a0 + *reinterpret_cast<const f4*>(src + (size_t)w * T.P);
+    }
+    *reinterpret_cast<f4*>(&red[sg][4 * l16]) = (a0 + a1) + (a2 + a3);
+  }
+  const bool loss_blk = T.nparams >= c0 && T.nparams < c0 + 64;  // (uniform over the workgroup)
+  float lsum = 0.f;
+  if (loss_blk && T.nlpart > 0) {
+    for (int j = tid; j < T.nlpart; j += TAIL_T) lsum += T.lpart[j];
+    lred[tid] = lsum;
+  }
+  __syncthreads();
+  if (loss_blk && T.nlpart > 0) {
+    for (int o = TAIL_T / 2; o > 0; o >>= 1) {
+      if (tid < o) lred[tid] += lred[tid + o];
+      __syncthreads();
+    }
+    lsum = lred[0];
+  }
+  if (T.nslab > 0) {  // 64 x TAIL_G partial sums -> 64 x 4 (every thread of the first four wavefronts adds sixteen)
+    float part = 0.f;
+    if (tid < 256) {
+#pragma unroll
+      for (int k = 0; k < TAIL_G / 4; ++k) part += red[(tid >> 6) * (TAIL_G / 4) + k][tid & 63];
+    }
+    __syncthreads();
+    if (tid < 256) red[tid >> 6][tid & 63] = part;
+    __syncthreads();
+  }
+  if (tid >= 64) return;
+  const int i = c0 + tid;
+  if (i > T.nparams) return;
+  if (i == T.nparams) {  // the loss slot
+    const float cur_f = T.g[i] + lsum;
+    if (!T.update) {
+      T.g[i] = cur_f;
+      return;
+    }
+    const double lr = T.sched[T.parity];
+    const double cur = (double)cur_f;
+    double best = T.sched[2], bad = T.sched[3], nred = T.sched[5];
+    if (cur < best * (1.0 - T.threshold)) { best = cur; bad = 0.0; }
+    else bad += 1.0;
+    double next = lr;
+    if (bad > (double)T.patience) {
+      const double cand = fmax(lr * T.factor, T.min_lr);
+      if (lr - cand > 1e-8) { next = cand; nred += 1.0; }
+      bad = 0.0;
+    }
+    T.sched[T.parity ^ 1] = next;
+    T.sched[2] = best; T.sched[3] = bad; T.sched[4] = cur; T.sched[5] = nred;
+    if (T.loss_log) *T.loss_log = cur_f;
+    T.g[i] = 0.f;
+    return;
+  }
+  float gi = T.g[i];
+  if (T.nslab > 0) gi += (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (!T.update) {
+    T.g[i] = gi;
+    return;
+  }
+  float pi = T.p[i];
+  {
+    const float step_size = (float)(T.sched[T.parity] * (double)T.inv_bc1);
+    if (T.wd != 0.f) gi = fmaf(T.wd, pi, gi);
+    const float mi = fmaf(T.b1, T.m[i], (1.f - T.b1) * gi);
+    const float vi = fmaf(T.b2, T.v[i], (1.f - T.b2) * gi * gi);
+    T.m[i] = mi;
+    T.v[i] = vi;
+    const float denom = sqrtf(vi) * T.inv_sqrt_bc2 + T.eps;
+    pi -= step_size * (mi / denom);
+    if (T.lower) pi = fmaxf(pi, T.lower[i]);
+    T.p[i] = pi;
+    T.g[i] = 0.f;
+  }
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < 6; ++k)
+    if (i >= T.poff[k]) seg = k;
+  const int k = seg >> 1, r = i - T.poff[seg];
+  if (seg & 1) {  // bias b_k[u]: bf[(t*4 + r4)*64 + lane] = b[16 t + 4 (lane >> 4) + r4] for the sixteen lanes of a quad
+    const int u = r;
+    float* dst = T.bf[k] + ((size_t)(u >> 4) * 4 + (u & 3)) * 64 + 16 * ((u & 15) >> 2);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[c] = pi;
+  } else {
+    const int in = T.in[k], uo = r / in, ui = r - uo * in;
+    {
+      const int sfw = k == 0 ? ui >> 2 : 4 * (ui >> 4) + (ui & 3);
+      const int q = k == 0 ? ui & 3 : (ui & 15) >> 2;
+      const int lane = 16 * q + (uo & 15);
+      T.wf[k][(((size_t)(uo >> 4) * (T.ks[k] >> 2) + (sfw >> 2)) * 64 + lane) * 4 + (sfw & 3)] = pi;
+    }
+    if (k > 0) {
+      const int st = T.natural[k] ? uo >> 2 : 4 * (uo >> 4) + (uo & 3);
+      const int q = T.natural[k] ? uo & 3 : (uo & 15) >> 2;
+      const int lane = 16 * q + (ui & 15);
+      T.wt[k][(((size_t)(ui >> 4) * (T.kst[k] >> 2) + (st >> 2)) * 64 + lane) * 4 + (st & 3)] = pi;
+    }
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad) {
   if (n_layers != 2 && n_layers != 3) return false;
@@ -836,7 +1049,7 @@ size_t fused_ws_bytes(int n_layers, const int32_t* dims, int64_t Q) {
 // lays the fragment buffers out in `ws`; do_pack launches the packing kernels (forward call), otherwise
 // the fragments packed by the matching forward call are reused (backward call)
 static int fused_pack(FusedArgs& A, int n_layers, const int32_t* dims, const float* const* W, const float* const* b,
-                      float* ws, bool do_pack, hipStream_t s) {
+                      float* ws, bool do_pack, hipStream_t s, PackArgs* layout = nullptr) {
   A.L = n_layers;
   A.in = dims[0];
   A.h1 = dims[1];
@@ -867,6 +1080,7 @@ static int fused_pack(FusedArgs& A, int n_layers, const int32_t* dims, const flo
   }
   if (do_pack) hipLaunchKernelGGL(pack_all_kernel, dim3(64), dim3(256), 0, s, PA);
   KR_HIP(hipGetLastError());
+  if (layout) *layout = PA;
   return KR_OK;
 }
 
@@ -883,7 +1097,7 @@ static void launch_by_act(int act, K&& fn) {
 
 int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
                       const float* const* b, const float* x, float* out, void* ws, hipStream_t s,
-                      const FusedLoss* fl) {
+                      const FusedLoss* fl, bool do_pack, int* n_partials) {
   FusedArgs A{};
   A.Q = Q; A.x = x; A.out = out;
   if (fl) {
@@ -891,7 +1105,7 @@ int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_
     A.lw = loss_weights(fl->inv_denom, fl->K);
     A.lpart = static_cast<float*>(fl->scratch);
   }
-  int rc = fused_pack(A, n_layers, dims, W, b, static_cast<float*>(ws), true, s);
+  int rc = fused_pack(A, n_layers, dims, W, b, static_cast<float*>(ws), do_pack, s);
   if (rc) return rc;
   const int64_t nblk = (Q + FR - 1) / FR;
   const int grid = (int)(nblk < 4096 ? nblk : 4096);
@@ -904,7 +1118,9 @@ int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_
     hipLaunchKernelGGL((mlp_fwd_fused_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
   });
   KR_HIP(hipGetLastError());
-  if (fl) {
+  if (fl && n_partials) {
+    *n_partials = grid;  // the caller's next kernel adds them up (train_tail_kernel)
+  } else if (fl) {
     hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, A.lpart, grid, fl->loss);
     KR_HIP(hipGetLastError());
   }
@@ -913,10 +1129,11 @@ int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_
 
 int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
                        const float* x, const float* dout, void* ws, float* const* dW, float* const* db,
-                       hipStream_t s) {
+                       hipStream_t s, FusedSlabs* leave) {
   FusedArgs A{};
   A.Q = Q; A.x = x; A.dout = dout;
-  for (int k = 0; k < n_layers; ++k) { A.dW[k] = dW[k]; A.db[k] = db[k]; }
+  if (!leave)
+    for (int k = 0; k < n_layers; ++k) { A.dW[k] = dW[k]; A.db[k] = db[k]; }
   int rc = fused_pack(A, n_layers, dims, W, nullptr, static_cast<float*>(ws), false, s);
   if (rc) return rc;
   const int64_t nblk = (Q + FR - 1) / FR;
@@ -942,12 +1159,19 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
   A.P = (P + 63) & ~63;
   A.slab = wsf;
   if (n_layers == 3) {
-    const int grid3 = (int)(nblk < F_MAXW ? nblk : F_MAXW);
+    const int waves3 = (int)(nblk < F_MAXW ? nblk : F_MAXW);
+    const int grid3 = (waves3 + WPB - 1) / WPB;  // wavefronts beyond the row blocks only take part in the sum
     A.nslab = grid3;
+    int lrc = KR_OK;
     launch_by_act(acts[0], [&](auto act) {
-      hipLaunchKernelGGL((mlp_bwd3a_kernel<decltype(act)::value>), dim3(grid3), dim3(64), 0, s, A);
-      hipLaunchKernelGGL((mlp_bwd3b_kernel<decltype(act)::value>), dim3(grid3), dim3(64), 0, s, A);
+      constexpr int a = decltype(act)::value;
+      const size_t la = sizeof(float) * WPB * B3A_LDS, lb = sizeof(float) * WPB * B3B_LDS;
+      if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_bwd3a_kernel<a>), la))) return;
+      if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_bwd3b_kernel<a>), lb))) return;
+      hipLaunchKernelGGL((mlp_bwd3a_kernel<a>), dim3(grid3), dim3(64 * WPB), la, s, A);
+      hipLaunchKernelGGL((mlp_bwd3b_kernel<a>), dim3(grid3), dim3(64 * WPB), lb, s, A);
     });
+    if (lrc) return lrc;
   } else {
     const int64_t streams = grid / nchunk;
     A.nslab = (int)(streams < nblk ? streams : nblk);  // streams beyond the row blocks exit without a slab
@@ -955,7 +1179,68 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
       hipLaunchKernelGGL((mlp_bwd2_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
     });
   }
+  if (leave) {  // the slabs stay where they are: train_tail_kernel sums them
+    leave->slab = A.slab; leave->nslab = A.nslab; leave->P = A.P; leave->nparams = A.nparams;
+    for (int k = 0; k < 6; ++k) leave->poff[k] = A.poff[k];
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+  }
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((P + 255) / 256, RG), dim3(256), 0, s, A);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
+
+// One epoch on one rank (kr_train_epoch).  phase 0: forward + loss, backward, tail with the update; 1: the same with the
+// tail stopping after the sums (gradients and loss complete in E.g); 2: only the update, from E.g as it stands.
+int fused_train_epoch(const FusedEpoch& E, hipStream_t s) {
+  const int n = E.n_layers;
+  const float* W[3];
+  const float* b[3];
+  size_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    W[k] = E.p + off; off += (size_t)E.dims[k] * E.dims[k + 1];
+    b[k] = E.p + off; off += (size_t)E.dims[k + 1];
+  }
+  const int nparams = (int)off;
+  FusedSlabs sl{};
+  int nlpart = 0;
+  int rc;
+  if (E.phase != 2) {
+    FusedLoss fl{E.base, E.target_rows, E.dout, E.g + nparams, E.loss_scratch, E.ds, E.inv_denom, E.K};
+    rc = fused_mlp_forward(E.Q, n, E.dims, E.acts, W, b, E.x, nullptr, E.ws, s, &fl, E.pack, &nlpart);
+    if (rc) return rc;
+    rc = fused_mlp_backward(E.Q, n, E.dims, E.acts, W, E.x, E.dout, E.ws, nullptr, nullptr, s, &sl);
+    if (rc) return rc;
+  }
+  FusedArgs A{};
+  PackArgs PA{};
+  rc = fused_pack(A, n, E.dims, W, b, static_cast<float*>(E.ws), false, s, &PA);
+  if (rc) return rc;
+  TailArgs T{};
+  T.slab = sl.slab; T.nslab = sl.nslab; T.nparams = nparams;
+  T.P = sl.nslab ? sl.P : (nparams + 63) & ~63;
+  T.p = E.p; T.g = E.g; T.m = E.m; T.v = E.v; T.lower = E.lower;
+  T.sched = E.sched; T.parity = (int)((E.step - 1) & 1);
+  const double bc1 = 1.0 - std::pow(E.beta1, (double)E.step), bc2 = 1.0 - std::pow(E.beta2, (double)E.step);
+  T.inv_bc1 = (float)(1.0 / bc1); T.b1 = (float)E.beta1; T.b2 = (float)E.beta2;
+  T.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2)); T.eps = (float)E.eps; T.wd = (float)E.weight_decay;
+  T.factor = E.factor; T.threshold = E.threshold; T.min_lr = E.min_lr; T.patience = E.patience;
+  T.loss_log = E.loss_log;
+  T.lpart = static_cast<const float*>(E.loss_scratch); T.nlpart = nlpart;
+  T.update = E.phase != 1;
+  T.L = n;
+  int P = 0;
+  for (int k = 0; k < n; ++k) {
+    T.poff[2 * k] = P; P += E.dims[k] * E.dims[k + 1];
+    T.poff[2 * k + 1] = P; P += E.dims[k + 1];
+  }
+  for (int k = 2 * n; k < 7; ++k) T.poff[k] = P;
+  for (int k = 0; k < n; ++k) {
+    T.in[k] = PA.in[k]; T.out[k] = PA.out[k]; T.ks[k] = PA.ks[k]; T.kst[k] = PA.kst[k]; T.natural[k] = PA.natural[k];
+    T.wf[k] = PA.wf[k]; T.bf[k] = PA.bf[k]; T.wt[k] = PA.wt[k];
+  }
+  const int grid = (nparams + 1 + 63) / 64;
+  hipLaunchKernelGGL(train_tail_kernel, dim3(grid), dim3(TAIL_T), 0, s, T);
   KR_HIP(hipGetLastError());
   return KR_OK;
 }

@@ -674,6 +674,57 @@ int kr_mlp_forward_loss(kr_handle* h, int64_t S, int K, int n_layers, const int3
   return kr_loss_rows_fwd_bwd(h, S, K, base, out, target_rows, denom, nullptr, loss, dout, stream);
 }
 
+int kr_train_epoch(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* dims, const int32_t* acts, float* params,
+                   float* grads, float* exp_avg, float* exp_avg_sq, const float* lower, double* sched, const float* x,
+                   int in_pad, const float* base, const float* target_rows, double denom, float* dout, void* ws,
+                   double beta1, double beta2, double eps, double weight_decay, int64_t step, double factor,
+                   int patience, double threshold, double min_lr, float* loss_log, int phase, int repack, void* stream) {
+  KR_CHECK_H(h);
+  if (S < 0 || K < 0) { set_error("negative size"); return KR_E_ARG; }
+  const int64_t Q = S * K;
+  int rc = check_mlp_shape(n_layers, dims);
+  if (rc) return rc;
+  KR_CHECK_PTR(acts);
+  if (phase < 0 || phase > 2) { set_error("kr_train_epoch: phase must be 0, 1 or 2"); return KR_E_ARG; }
+  if (step < 1) { set_error("kr_train_epoch: step counts from 1"); return KR_E_ARG; }
+  if (!(factor > 0.0 && factor < 1.0) || patience < 0) { set_error("kr_train_epoch: need 0 < factor < 1, patience >= 0"); return KR_E_ARG; }
+  if (Q <= 0 || Q > (int64_t)1 << 30) { set_error("kr_train_epoch: need 0 < S * K <= 2^30"); return KR_E_ARG; }
+  if (!h->fused_mlp || dims[n_layers] != 25 || !fused_mlp_supported(n_layers, dims, acts, in_pad)) {
+    set_error("kr_train_epoch serves the networks of the fused training kernels (28 -> H -> 25 and 28 -> H1 -> H2 -> 25 with "
+              "H1, H2 <= 64, one activation, none after the last layer); use kr_mlp_forward_loss / kr_mlp_backward / "
+              "kr_adam_plateau_step for others");
+    return KR_E_UNSUPPORTED;
+  }
+  KR_CHECK_PTR(params); KR_CHECK_PTR(grads); KR_CHECK_PTR(exp_avg); KR_CHECK_PTR(exp_avg_sq); KR_CHECK_PTR(sched);
+  KR_CHECK_PTR(ws);
+  if (phase != 2) { KR_CHECK_PTR(x); KR_CHECK_PTR(base); KR_CHECK_PTR(target_rows); KR_CHECK_PTR(dout); }
+  if (phase != 2 && !(denom > 0)) { set_error("denom must be positive"); return KR_E_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
+  if (!h->loss_scratch) KR_HIP(hipMalloc(&h->loss_scratch, 4096 * sizeof(float)));
+  uint64_t net = 1469598103934665603ull;  // FNV-1a over the shape
+  for (int k = 0; k <= n_layers; ++k) net = (net ^ (uint64_t)dims[k]) * 1099511628211ull;
+  const bool current = !repack && h->frag_ws == ws && h->frag_params == params && h->frag_net == net;
+  FusedEpoch E{};
+  E.Q = Q; E.K = K; E.n_layers = n_layers; E.dims = dims; E.acts = acts;
+  E.p = params; E.g = grads; E.m = exp_avg; E.v = exp_avg_sq; E.lower = lower; E.sched = sched;
+  E.x = x; E.base = base; E.target_rows = target_rows; E.dout = dout; E.ws = ws; E.loss_scratch = h->loss_scratch;
+  E.ds = (float)h->derived.ds; E.inv_denom = phase != 2 ? (float)(1.0 / denom) : 0.f;
+  E.beta1 = beta1; E.beta2 = beta2; E.eps = eps; E.weight_decay = weight_decay;
+  E.factor = factor; E.threshold = threshold; E.min_lr = min_lr; E.patience = patience;
+  E.step = step; E.loss_log = loss_log; E.phase = phase;
+  E.pack = !current;
+  if (phase == 2 && !current) {
+    // the update scatters into fragments that must already hold every other slot (padding included)
+    set_error("kr_train_epoch: phase 2 needs the fragments of a phase 1 call with the same ws / params");
+    return KR_E_ARG;
+  }
+  rc = fused_train_epoch(E, s);
+  if (rc) { h->frag_ws = nullptr; return rc; }
+  h->frag_ws = ws; h->frag_params = params; h->frag_net = net;
+  return KR_OK;
+}
+
 int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                  const float* lower, double lr, double beta1, double beta2, double eps, double weight_decay,
                  int64_t step, int64_t n_zero, void* stream) {
@@ -684,6 +735,7 @@ int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* ex
   if (n) { KR_CHECK_PTR(params); KR_CHECK_PTR(exp_avg); KR_CHECK_PTR(exp_avg_sq); }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc_order_ = order_stream(h, s)) return rc_order_;
+  if (params == h->frag_params) h->frag_ws = nullptr;  // (kr_train_epoch's fragment copies no longer match)
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
   int grid = (int)((n_zero + 255) / 256);
   if (grid > 1024) grid = 1024;
@@ -705,6 +757,7 @@ int kr_adam_plateau_step(kr_handle* h, int64_t n, float* params, float* grads, f
   if (n) { KR_CHECK_PTR(params); KR_CHECK_PTR(exp_avg); KR_CHECK_PTR(exp_avg_sq); }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc_order_ = order_stream(h, s)) return rc_order_;
+  if (params == h->frag_params) h->frag_ws = nullptr;  // (kr_train_epoch's fragment copies no longer match)
   const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
   int grid = (int)((n_zero + 255) / 256);
   if (grid > 1024) grid = 1024;

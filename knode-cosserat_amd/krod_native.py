@@ -24,6 +24,7 @@ KR_EULER, KR_RK4 = 0, 1
 ACT_NONE, ACT_TANH, ACT_SOFTPLUS, ACT_RELU, ACT_ELU = range(5)
 ST_CONVERGED, ST_MAXIT, ST_NONFINITE = 0, 1, 2
 KR_MAX_LAYERS = 8
+KR_E_ARG, KR_E_UNSUPPORTED = -1, -4
 
 # reference row (0..24 of [y; z]) -> packed slot, see knode_rod.h
 ROW_TO_SLOT = np.array([12 + r for r in range(13)] + [r - 13 for r in range(13, 19)] + [6 + (r - 19) for r in range(19, 25)])
@@ -94,6 +95,9 @@ _PROTOS = {
                             C.c_double, _i64, _i64, _vp]),
     "kr_adam_plateau_step": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double,
                                     C.c_double, _i64, _i64, _i64, C.c_double, _int, C.c_double, C.c_double, _vp, _vp]),
+    "kr_train_epoch": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp,
+                              C.c_double, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double,
+                              _int, C.c_double, C.c_double, _vp, _int, _int, _vp]),
     "kr_loss_rows_fwd_bwd": (_int, [_vp, _i64, _int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "kr_estimate_ws_bytes": (C.c_size_t, [_i64, _int]),
     "kr_estimate_state": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -104,7 +108,7 @@ _lib = None
 
 
 class KrError(RuntimeError):
-    pass
+    code = 0
 
 
 def load():
@@ -132,7 +136,9 @@ def load():
 def check(rc: int):
     if rc != 0:
         msg = load().kr_last_error()
-        raise KrError(f"libknode_rod error {rc}: {msg.decode() if msg else '?'}")
+        err = KrError(f"libknode_rod error {rc}: {msg.decode() if msg else '?'}")
+        err.code = rc
+        raise err
 
 
 def dtype_code(t) -> int:

@@ -120,6 +120,9 @@ class KnodeTrainer:
         # epilogue of the forward kernel and predictions() evaluates them on demand
         self.keep_pred = keep_pred
         self.group = group
+        self.fused_epoch = True   # kr_train_epoch (one call per epoch) where the network is one the fused kernels serve
+        self._repack = False
+        self._param_versions = None
         self.time_allreduce = False
         self.allreduce_events = []
         self.clamp_weights = clamp_weights
@@ -281,10 +284,70 @@ class KnodeTrainer:
                     for k in range(self.n):
                         self.params[2 * k].clamp_(min=0)
 
+    def _epoch_call(self, phase):
+        """kr_train_epoch: the epoch (phase 0) or its two halves around the all-reduce (1, 2) as 3-4 kernel launches."""
+        h, sc = self.h, self.scheduler
+        e = sc.steps
+        if e >= self.loss_log.numel():
+            self.loss_log = torch.cat([self.loss_log, torch.zeros_like(self.loss_log)])
+        kn.check(h.lib.kr_train_epoch(
+            h._h, self.S, self.K, self.n, self.dims_c, self.acts_c, kn._ptr(self.flat_p), kn._ptr(self.bucket.flat),
+            kn._ptr(self.exp_avg), kn._ptr(self.exp_avg_sq), kn._ptr(self.lower) if self.clamp_weights else None,
+            kn._ptr(sc.buf), kn._ptr(self.x), self.in_pad, kn._ptr(self.base), kn._ptr(self.target_rows),
+            float(self.steps), kn._ptr(self.dout), kn._ptr(self.ws), self.betas[0], self.betas[1], self.adam_eps,
+            self.weight_decay, self.adam_step + 1, sc.factor, sc.patience, sc.threshold, sc.min_lr,
+            self.loss_log.data_ptr() + 4 * e, phase, 1 if self._repack else 0, kn._stream()))
+        if phase != 2:
+            self._repack = False
+        if phase != 1:
+            self.adam_step += 1
+            sc.steps = self.adam_step
+
+    def weights_changed(self):
+        """Tell the trainer that the parameters were written from outside (a loaded checkpoint): the next epoch packs the
+        kernels' weight fragments afresh instead of relying on the copies its own updates maintain."""
+        self._repack = True
+
+    def _fused_epoch(self):
+        """The single-call epoch where it applies; False = not served (the caller takes the separate calls)."""
+        if not (self.fused_epoch and self.native_adam and self.device_plateau and not self.keep_pred and self.Q > 0):
+            return False
+        import torch.distributed as dist
+        dp = (self.group is not False and dist.is_available() and dist.is_initialized()
+              and dist.get_world_size(self.group) > 1)
+        # in-place writes to the parameters from outside (load_state_dict, copy_, clamp_) bump torch's version counters;
+        # the kernels' own updates do not
+        ver = tuple(p._version for p in self.params) + (self.flat_p._version,)
+        if ver != self._param_versions:
+            self._repack = self._repack or self._param_versions is not None
+            self._param_versions = ver
+        try:
+            self._epoch_call(1 if dp else 0)
+        except kn.KrError as err:
+            if err.code != kn.KR_E_UNSUPPORTED:
+                raise
+            self.fused_epoch = False  # a network the fused kernels do not serve
+            return False
+        if dp:
+            if self.time_allreduce:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.bucket.all_reduce(self.group)
+                e1.record()
+                self.allreduce_events.append((e0, e1))
+            else:
+                self.bucket.all_reduce(self.group)
+            self._epoch_call(2)
+        return True
+
     def step(self, sync_loss=True):
         """One epoch of physics_train.py (:313-401): forward, loss, backward, all-reduce, Adam, plateau schedule, clamp.
         With the device-side schedule nothing in here waits for the GPU unless ``sync_loss`` asks for the loss as a
         float (``losses()`` returns the whole history later); otherwise the schedule is torch's and needs the value."""
+        if self._fused_epoch():
+            if sync_loss:
+                return float(self.loss_log[self.scheduler.steps - 1].item())
+            return None
         loss = self.loss_and_grads()
         if self.device_plateau:
             self.apply_update()  # (reads the loss slot on the device, logs it, steps the schedule, clears the slot)

@@ -160,3 +160,122 @@ def test_three_layer_networks_every_activation(torch_cuda, monkeypatch, act, dty
         assert rel_l2(out["traj"][b], want[: T + 1, :25]) < tol, (act, dtype, b)
         if b == 0:
             assert rel_l2(plain[: T + 1, :25], want[: T + 1, :25]) > 1e-4
+
+
+# ---- kr_train_epoch: the epoch as one call (3-4 launches) -------------------------------------------------------------
+def _epoch_trainer(torch, layers, M=24, T=12, N=20, kp=(5, 11, 19), seed=5, act="elu"):
+    """A KnodeTrainer on M short trajectories simulated by the library itself (MLP off), network 28 -> layers -> 25."""
+    import torch.nn as nn
+    import cosserat_oracle as orc
+    from cosserat_ode_torch import CosseratRodTorch
+    from knode import setup_robot, simulate_batch
+    from krod_train import KnodeTrainer
+    r = make_robot(None, N)
+    ctl = orc.batch_sine_controls(M, T, r.del_t, 77)
+    traj = torch.as_tensor(simulate_batch(r, ctl, dtype="f32")["traj"][:, :T], device=DEV).float().contiguous()
+    rob = CosseratRodTorch(DEV, layers[0])
+    setup_robot(rob, "damping")
+    rob.N = N
+    rob.compute_intermediate_terms()
+    torch.manual_seed(seed)
+    A = {"elu": nn.ELU, "tanh": nn.Tanh, "softplus": nn.Softplus, "relu": nn.ReLU}[act]
+    sizes = [28] + list(layers) + [25]
+    mods = []
+    for a, b in zip(sizes[:-1], sizes[1:]):
+        mods += [nn.Linear(a, b), A()]
+    mods = mods[:-1]
+    for m in mods:
+        if isinstance(m, nn.Linear):
+            rob.non_negative_normal_init(m, 0.01, 0.01)
+            nn.init.normal_(m.bias, 0.0, 0.01)
+    rob.nn_models = nn.ModuleList(mods).to(DEV)
+    return KnodeTrainer(rob, traj, torch.as_tensor(ctl, device=DEV).float().contiguous(), list(kp), keep_pred=False)
+
+
+@pytest.mark.parametrize("layers,act", [([64, 64], "elu"), ([64, 48], "tanh"), ([512], "elu"), ([40], "softplus")])
+def test_train_epoch_equals_the_separate_calls(torch_cuda, layers, act):
+    """kr_train_epoch (forward + loss, backward, ONE tail launch: slab sum, loss sum, Adam, clamp, plateau schedule,
+    fragment update) against kr_mlp_forward_loss + kr_mlp_backward + kr_adam_plateau_step on the same data: the same
+    losses and parameters to summation order (the separate path adds its slabs with float atomics)."""
+    torch = torch_cuda
+    a = _epoch_trainer(torch, layers, act=act)
+    b = _epoch_trainer(torch, layers, act=act)
+    b.fused_epoch = False
+    for _ in range(12):
+        a.step(sync_loss=False)
+        b.step(sync_loss=False)
+    torch.cuda.synchronize()
+    assert a.fused_epoch and a.adam_step == 12 and a.scheduler.steps == 12
+    la, lb = np.array(a.losses()), np.array(b.losses())
+    assert la.shape == lb.shape == (12,) and la[-1] < la[0]
+    assert np.max(np.abs(la - lb) / np.abs(lb)) < 5e-6, (la, lb)
+    pa, pb = a.flat_p.cpu().numpy(), b.flat_p.cpu().numpy()
+    assert np.max(np.abs(pa - pb)) < 2e-6 * max(1.0, np.abs(pb).max())
+    assert float(a.bucket.flat.abs().max()) == 0.0                 # gradients and loss slot left zeroed
+    assert a.scheduler.get_last_lr() == b.scheduler.get_last_lr()
+    assert np.array_equal(a.exp_avg.cpu().numpy() != 0, b.exp_avg.cpu().numpy() != 0)
+
+
+@pytest.mark.parametrize("layers", [[64, 64], [512]])
+def test_train_epoch_is_reproducible_and_its_fragments_track_the_updates(torch_cuda, layers):
+    """The tail kernel writes every updated parameter into the MFMA fragment buffers of the next epoch.  Run (a) relies on
+    those copies, run (b) has the fragments packed afresh from the parameter vector before every epoch, run (c) splits
+    every epoch into the two halves a data-parallel job puts around its all-reduce (phase 1, phase 2): all three must
+    agree BIT FOR BIT (fixed summation order everywhere - no atomics in this path)."""
+    torch = torch_cuda
+    runs = []
+    for mode in ("carried", "repacked", "halves"):
+        t = _epoch_trainer(torch, layers)
+        for _ in range(8):
+            if mode == "repacked":
+                t.weights_changed()
+            if mode == "halves":
+                t._epoch_call(1)
+                t._epoch_call(2)
+            else:
+                t.step(sync_loss=False)
+        torch.cuda.synchronize()
+        runs.append((t.flat_p.cpu().numpy().copy(), np.array(t.losses()), t.exp_avg_sq.cpu().numpy().copy()))
+    for other in runs[1:]:
+        for x, y in zip(runs[0], other):
+            assert np.array_equal(x, y)
+
+
+def test_train_epoch_notices_parameters_written_from_outside(torch_cuda):
+    """load_state_dict / copy_ on the parameters between epochs: the trainer sees torch's version counters move and has
+    the fragments packed afresh; a separate kr_adam_plateau_step on the same vector invalidates them in the library."""
+    torch = torch_cuda
+    a = _epoch_trainer(torch, [64, 64])
+    b = _epoch_trainer(torch, [64, 64])
+    b.fused_epoch = False
+    for t in (a, b):
+        for _ in range(3):
+            t.step(sync_loss=False)
+    sd = {k: v.clone() * 0.5 for k, v in a.robot.nn_models.state_dict().items()}
+    for t in (a, b):
+        t.robot.nn_models.load_state_dict(sd)
+        for _ in range(3):
+            t.step(sync_loss=False)
+    # mixed use: one epoch through the separate calls on trainer a, then the single call again
+    a.fused_epoch = False
+    a.step(sync_loss=False)
+    a.fused_epoch = True
+    a.step(sync_loss=False)
+    b.step(sync_loss=False)
+    b.step(sync_loss=False)
+    torch.cuda.synchronize()
+    la, lb = np.array(a.losses()), np.array(b.losses())
+    assert np.max(np.abs(la - lb) / np.abs(lb)) < 5e-6, (la, lb)
+
+
+def test_train_epoch_argument_errors(torch_cuda):
+    torch = torch_cuda
+    import krod_native as kn
+    t = _epoch_trainer(torch, [64, 64])
+    with pytest.raises(kn.KrError, match="phase 2 needs"):
+        t._epoch_call(2)                       # no phase 1 before it: nothing to scatter into
+    with pytest.raises(kn.KrError, match="phase must be"):
+        t._epoch_call(3)
+    u = _epoch_trainer(torch, [96, 64])        # first hidden layer wider than the three-layer kernels serve
+    u.step(sync_loss=False)
+    assert u.fused_epoch is False and u.adam_step == 1

@@ -12,7 +12,7 @@ for cfg in cfg3 cfg4; do
 import csv, sys
 for row in csv.DictReader(open(sys.argv[1])):
     n = row["Name"]
-    if any(k in n for k in ("mlp_", "loss", "adam", "pack_", "reduce_")):
+    if any(k in n for k in ("mlp_", "loss", "adam", "pack_", "reduce_", "tail")):
         print(f"{n[:60]:60s} calls {row['Calls']:>5s} avg {float(row['AverageNs'])/1e3:8.1f} us")
 PY
 done
