@@ -292,6 +292,7 @@ struct FusedEpoch {
   bool pack;
 };
 int fused_train_epoch(const FusedEpoch& E, hipStream_t s);
+void fused_set_debug(void* dev_u64x48);  // diagnostic build: where the fused kernels add their phase stamps
 
 // kr_ode.hip
 template <typename T>

@@ -56,6 +56,20 @@ struct FChunk {
   f4 a[4][FT];  // [unit tile][sample tile]
 };
 
+// diagnostic build (make dbgf; tools/fused_stamps.py): cycle counts of the phases of a row block, summed over all
+// wavefronts into the buffer given to kr_debug_buffer
+#ifdef KR_FUSED_STAMPS
+#define FSTAMP_DECL unsigned long long fst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ft0
+#define FSTAMP_T0 do { __builtin_amdgcn_sched_barrier(0); ft0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); fst[k] += t_ - ft0; ft0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FSTAMP_OUT(kern, wave) do { if (A.stamps && lane == 0) { for (int k_ = 0; k_ < 12; ++k_) A.stamps[((size_t)(kern) * 4096 + (wave)) * 12 + k_] += fst[k_]; } } while (0)
+#else
+#define FSTAMP_DECL
+#define FSTAMP_T0 do { } while (0)
+#define FSTAMP(k) do { } while (0)
+#define FSTAMP_OUT(kern, wave) do { } while (0)
+#endif
+
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // Every MFMA kernel of this file runs ONE wavefront per workgroup (dim3(64)), so all LDS hand-offs are between lanes of
 // one wavefront, whose LDS instructions execute in order: a wavefront-scope fence (a compiler barrier) is enough.  The
@@ -356,7 +370,10 @@ struct FusedArgs {
                          // fence per workgroup for an in-kernel arrival count writes the L2 back each time - 180 us)
   float lds;             // arc-length step: pred = base + [ds out[:19], out[19:]]
   LossWeights lw;
+  unsigned long long* stamps;  // diagnostic build only
 };
+static unsigned long long* g_fused_stamps = nullptr;
+void fused_set_debug(void* p) { g_fused_stamps = static_cast<unsigned long long*>(p); }
 
 // ---- forward -------------------------------------------------------------------------------------------
 template <int ACT>
@@ -367,6 +384,11 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
   const int64_t nblk = (A.Q + FR - 1) / FR;
   const bool with_loss = A.lbase != nullptr;
   float loss_part = 0.f;
+  FSTAMP_DECL;
+#ifdef KR_FUSED_STAMPS
+  const unsigned long long fkernel0 = __builtin_amdgcn_s_memtime();
+#endif
+  FSTAMP_T0;
   for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
     stage_rows<F_LDO>(A.x, rb * FR, A.Q, tx, lane);  // (pitch 36: the operand reads below hit 2 banks, not 16)
     // fused loss: the block's base and target rows (FR x 25 contiguous floats of each array; a row block starts at a
@@ -395,6 +417,7 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
       }
     }
     fsync();
+    FSTAMP(0);  // x rows landed in the tile (the wait for the block's loads is here)
     float bin[FT][8];
 #pragma unroll
     for (int s = 0; s < FT; ++s)
@@ -420,14 +443,20 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
     } else {
       FChunk h1, h2;
       chunk_set_bias(h1, A.bfr[0], 0, lane);
+      FSTAMP(1);
       facc<4, 8>(h1.a, A.wf[0], 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      FSTAMP(2);
       chunk_act_only<ACT>(h1);
       chunk_dump(A.a1d, rb, h1, lane);
       chunk_set_bias(h2, A.bfr[1], 0, lane);
+      FSTAMP(3);
       facc<4, 16>(h2.a, A.wf[1], A.ks[1], 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
+      FSTAMP(4);
       chunk_act_only<ACT>(h2);
       chunk_dump(A.a2d, rb, h2, lane);
+      FSTAMP(5);
       facc<2, 16>(oacc, A.wf[2], A.ks[2], 0, 0, lane, [&](int s, int k) { return h2.a[k >> 2][s][k & 3]; });
+      FSTAMP(6);
     }
     fsync();
     // outputs -> row-major tile (pitch F_LDO: one lane reads a whole row below; 36 keeps the rows 16-byte aligned and
@@ -452,6 +481,7 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
       }
     }
     fsync();
+    FSTAMP(7);  // outputs, base and target rows in their tiles
     if (with_loss) {
       // one row per lane (lanes 0 .. FR-1): prediction, four-term loss, gradient with respect to the outputs (written
       // over them).  The upper half of the wave is idle here, so it takes one of the two quaternion_to_euler calls
@@ -484,6 +514,7 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
       }
       fsync();
     }
+    FSTAMP(8);  // loss epilogue
     {
       constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;  // lanes per row, 16-byte pieces per lane
       const int rl = lane % FR, part = lane / FR;
@@ -496,7 +527,15 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
       }
     }
     fsync();
+    FSTAMP(9);  // gradient rows stored
+#ifdef KR_FUSED_STAMPS
+    fst[11] += 1;
+#endif
   }
+#ifdef KR_FUSED_STAMPS
+  fst[10] = __builtin_amdgcn_s_memtime() - fkernel0;
+#endif
+  FSTAMP_OUT(0, blockIdx.x);
   if (with_loss) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) loss_part += __shfl_xor(loss_part, m, 64);
@@ -692,8 +731,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3a_kernel(const FusedArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) aW3[o][i] = f4{0.f, 0.f, 0.f, 0.f};
   float pb2 = 0.f, pbo = 0.f;  // bias gradients of unit `lane`: row sums of the dZ2 / dOUT^T tiles
+  FSTAMP_DECL;
+  FSTAMP_T0;
   for (int64_t rb = wave0; rb < nblk; rb += nwaves) {
     stage_rows_T(A.dout, rb * FR, A.Q, ts, lane);
+    FSTAMP(0);
     {
       FChunk h;
       chunk_undump(h, A.a1d, rb, lane);
@@ -702,8 +744,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3a_kernel(const FusedArgs 
       chunk_to_T(tv, h, lane);  // A2
     }
     fsync();
+    FSTAMP(1);
     if (lane < 32) pbo += row_sum_T(ts, lane);
     wgrad_T<2, 4>(aW3, ts, tv, lane);  // dW3 += dOUT^T A2
+    FSTAMP(2);
     FChunk d2;
     chunk_zero(d2);
     {
@@ -711,15 +755,19 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3a_kernel(const FusedArgs 
       load_bops_T(bd, ts, lane);
       facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
     }
+    FSTAMP(3);
     chunk_mul_grad_T<ACT>(d2, tv, lane);
     chunk_dump(A.dz2, rb, d2, lane);
     fsync();
     chunk_to_T(tv, d2, lane);  // dZ2 (A2 is consumed)
     fsync();
+    FSTAMP(4);
     pb2 += row_sum_T(tv, lane);
     wgrad_T<4, 4>(aW2, tv, tu, lane);  // dW2 += dZ2^T A1
     fsync();
+    FSTAMP(5);
   }
+  FSTAMP_OUT(1, wave0);
   wg_tree_sum(aW2, aW3, pb2, pbo, wg_lds, wv, lane);
   if (wv != 0) return;
   float* slab = A.slab + (size_t)blockIdx.x * A.P;
@@ -742,8 +790,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3b_kernel(const FusedArgs 
 #pragma unroll
     for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
   float pb1 = 0.f;
+  FSTAMP_DECL;
+  FSTAMP_T0;
   for (int64_t rb = wave0; rb < nblk; rb += nwaves) {
     stage_rows_T(A.x, rb * FR, A.Q, ts, lane);
+    FSTAMP(0);
     FChunk d2;
     chunk_undump(d2, A.dz2, rb, lane);
     {
@@ -751,18 +802,23 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3b_kernel(const FusedArgs 
       chunk_undump(h1, A.a1d, rb, lane);
       chunk_to_T(tu, h1, lane);  // A1
     }
+    FSTAMP(1);
     FChunk d1;
     chunk_zero(d1);
     facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
     fsync();
+    FSTAMP(2);
     chunk_mul_grad_T<ACT>(d1, tu, lane);
     fsync();
     chunk_to_T(tu, d1, lane);  // dZ1 (A1 is consumed)
     fsync();
+    FSTAMP(3);
     pb1 += row_sum_T(tu, lane);
     wgrad_T<4, 2>(aW1, tu, ts, lane);  // dW1 += dZ1^T X
     fsync();
+    FSTAMP(4);
   }
+  FSTAMP_OUT(2, wave0);
   {
     f4 none[1][1] = {{f4{0.f, 0.f, 0.f, 0.f}}};
     float unused = 0.f;
@@ -1051,6 +1107,7 @@ size_t fused_ws_bytes(int n_layers, const int32_t* dims, int64_t Q) {
 static int fused_pack(FusedArgs& A, int n_layers, const int32_t* dims, const float* const* W, const float* const* b,
                       float* ws, bool do_pack, hipStream_t s, PackArgs* layout = nullptr) {
   A.L = n_layers;
+  A.stamps = g_fused_stamps;
   A.in = dims[0];
   A.h1 = dims[1];
   A.h2 = n_layers == 3 ? dims[2] : 0;

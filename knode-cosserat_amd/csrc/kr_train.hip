@@ -719,6 +719,7 @@ int kr_train_epoch(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* 
     set_error("kr_train_epoch: phase 2 needs the fragments of a phase 1 call with the same ws / params");
     return KR_E_ARG;
   }
+  fused_set_debug(h->dbg);
   rc = fused_train_epoch(E, s);
   if (rc) { h->frag_ws = nullptr; return rc; }
   h->frag_ws = ws; h->frag_params = params; h->frag_net = net;
