@@ -376,11 +376,28 @@ static unsigned long long* g_fused_stamps = nullptr;
 void fused_set_debug(void* p) { g_fused_stamps = static_cast<unsigned long long*>(p); }
 
 // ---- forward -------------------------------------------------------------------------------------------
-template <int ACT>
-__global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A) {
-  __shared__ __attribute__((aligned(16))) float tx[FR * F_LDO];
-  __shared__ __attribute__((aligned(16))) float tbt[2 * FR * 25];  // fused loss: base rows, target rows of the block
-  const int lane = threadIdx.x;
+// Three-layer networks (H1, H2 <= 64) keep their forward fragments in the LDS, one copy per workgroup of FW3 wavefronts
+// (mlp_fwd3_kernel): 8 + 16 + 8 KB of products' A operands and the three bias vectors in compact form.  Fetched from
+// memory (L2) inside the products they queue behind the row block's own loads in the wavefront's in-order return path:
+// stamps (tools/fused_stamps.py) showed a wavefront spending 35 k cycles on a row block whose 256 products take 8 k.
+constexpr int FW3 = 8;
+constexpr int FW3_W0 = 0, FW3_W1 = 4 * 8 * 64, FW3_W2 = FW3_W1 + 4 * 16 * 64, FW3_B = FW3_W2 + 2 * 16 * 64;  // floats
+constexpr int FW3_FRAG = FW3_B + 64 + 64 + 32;
+constexpr int FW3_WAVE = 2 * FR * F_LDX + 2 * FR * 25;  // per wavefront: two x tiles (the output tile lies over the current one), base + target rows
+
+// LDS-direct load of 16 bytes per lane: lane l's bytes land at LDS byte address lds_byte + 16 l (wave-uniform base in M0)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_byte)
+               : "memory");
+}
+
+// the row blocks first, first + stride, ... of one wavefront; WLDS: fragments at `wl` in the LDS (three layers)
+template <int ACT, bool WLDS>
+__device__ __forceinline__ void fwd_rows(const FusedArgs& A, float* tx, float* tbt, const float* wl, int lane, int64_t first,
+                                         int64_t stride, int part) {
   const int64_t nblk = (A.Q + FR - 1) / FR;
   const bool with_loss = A.lbase != nullptr;
   float loss_part = 0.f;
@@ -389,8 +406,40 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
   const unsigned long long fkernel0 = __builtin_amdgcn_s_memtime();
 #endif
   FSTAMP_T0;
-  for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
-    stage_rows<F_LDO>(A.x, rb * FR, A.Q, tx, lane);  // (pitch 36: the operand reads below hit 2 banks, not 16)
+  // WLDS: the x rows of the NEXT block travel while this one is worked on, by LDS-direct loads (no registers, and nothing
+  // the compiler would have to wait for at the loop head: with ordinary loads carried around the loop it drains the
+  // whole queue there - s_waitcnt vmcnt(0) - and that queue ends with the gradient rows just stored).  The x tile is
+  // row-major with pitch 32 and an XOR swizzle of its 16-byte pieces, applied on the SOURCE side (an LDS-direct load
+  // writes lane-linear); two tiles per wavefront; the output tile of a block (pitch OP) lies over its x tile.
+  constexpr int OP = WLDS ? 25 : F_LDO;
+  float* xcur = tx;
+  auto x_request = [&](int64_t rbn, float* buf) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)buf);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int P = 64 * j + lane, row = P >> 3, kp = P & 7;
+      int64_t grow = rbn * FR + row;
+      grow = grow < A.Q ? grow : A.Q - 1;  // rows past the end repeat the last one (their results are never used)
+      glds16(A.x + grow * F_LDX + 4 * (kp ^ (row & 7)), base + 1024 * j);
+    }
+  };
+  if constexpr (WLDS) {
+    if (first < nblk) x_request(first, tx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  bool first_block = true;
+  for (int64_t rb = first; rb < nblk; rb += stride) {
+    if constexpr (WLDS) {
+      // x of this block was requested a block ago; younger in the queue: this wavefront's 16 dump stores and 4 row
+      // stores of the last block (and its base / target loads, long consumed) - they may stay in flight
+      if (!first_block) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      first_block = false;
+      FSTAMP(10);
+      if (rb + stride < nblk) x_request(rb + stride, xcur == tx ? tx + FR * F_LDX : tx);
+      FSTAMP(11);
+    } else {
+      stage_rows<F_LDO>(A.x, rb * FR, A.Q, tx, lane);  // (pitch 36: the operand reads below hit 2 banks, not 16)
+    }
     // fused loss: the block's base and target rows (FR x 25 contiguous floats of each array; a row block starts at a
     // multiple of 3200 bytes) are requested now, as 16-byte pieces into registers, and go to LDS only when the
     // epilogue needs them - their latency hides behind the layers
@@ -422,17 +471,50 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
 #pragma unroll
     for (int s = 0; s < FT; ++s)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) bin[s][k] = tx[(16 * s + (lane & 15)) * F_LDO + 4 * k + (lane >> 4)];
+      for (int k = 0; k < 8; ++k)
+        bin[s][k] = WLDS ? xcur[(16 * s + (lane & 15)) * F_LDX + 4 * (k ^ (lane & 7)) + (lane >> 4)]
+                         : tx[(16 * s + (lane & 15)) * F_LDO + 4 * k + (lane >> 4)];
     f4 oacc[2][FT];
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       f4 b;
+      if constexpr (WLDS) {
+        b = *reinterpret_cast<const f4*>(wl + FW3_B + 128 + 16 * o + 4 * (lane >> 4));
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) b[r] = A.bfr[A.L - 1][((size_t)o * 4 + r) * 64 + lane];
+        for (int r = 0; r < 4; ++r) b[r] = A.bfr[A.L - 1][((size_t)o * 4 + r) * 64 + lane];
+      }
 #pragma unroll
       for (int s = 0; s < FT; ++s) oacc[o][s] = b;
     }
-    if (A.L == 2) {
+    if constexpr (WLDS) {
+      FChunk h1, h2;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const f4 b = *reinterpret_cast<const f4*>(wl + FW3_B + 16 * o + 4 * (lane >> 4));
+#pragma unroll
+        for (int s = 0; s < FT; ++s) h1.a[o][s] = b;
+      }
+      FSTAMP(1);
+      facc<4, 8>(h1.a, wl + FW3_W0, 8, 0, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      FSTAMP(2);
+      chunk_act_only<ACT>(h1);
+      chunk_dump(A.a1d, rb, h1, lane);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const f4 b = *reinterpret_cast<const f4*>(wl + FW3_B + 64 + 16 * o + 4 * (lane >> 4));
+#pragma unroll
+        for (int s = 0; s < FT; ++s) h2.a[o][s] = b;
+      }
+      FSTAMP(3);
+      facc<4, 16>(h2.a, wl + FW3_W1, 16, 0, 0, lane, [&](int s, int k) { return h1.a[k >> 2][s][k & 3]; });
+      FSTAMP(4);
+      chunk_act_only<ACT>(h2);
+      chunk_dump(A.a2d, rb, h2, lane);
+      FSTAMP(5);
+      facc<2, 16>(oacc, wl + FW3_W2, 16, 0, 0, lane, [&](int s, int k) { return h2.a[k >> 2][s][k & 3]; });
+      FSTAMP(6);
+    } else if (A.L == 2) {
       for (int c = 0; c < A.c1; ++c) {
         FChunk h;
         chunk_set_bias(h, A.bfr[0], 4 * c, lane);
@@ -468,7 +550,11 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int u = 16 * o + 4 * (lane >> 4) + r;
-          tx[(16 * s + (lane & 15)) * F_LDO + u] = u < A.nout ? oacc[o][s][r] : 0.f;
+          if constexpr (WLDS) {
+            if (u < 25) xcur[(16 * s + (lane & 15)) * OP + u] = oacc[o][s][r];
+          } else {
+            tx[(16 * s + (lane & 15)) * F_LDO + u] = u < A.nout ? oacc[o][s][r] : 0.f;
+          }
         }
     if (with_loss) {
 #pragma unroll
@@ -486,6 +572,8 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
       // one row per lane (lanes 0 .. FR-1): prediction, four-term loss, gradient with respect to the outputs (written
       // over them).  The upper half of the wave is idle here, so it takes one of the two quaternion_to_euler calls
       // of a row: lane FR + r converts the target quaternion of row r while lane r converts the predicted one.
+      // (Giving the upper lane the 21 plain components as well was measured: the two halves then run different code, one
+      // after the other - 10.7 k cycles per block instead of 7.4 k.)
       static_assert(FR == 32, "lane <-> row map of the loss epilogue");
       const int rl = lane & (FR - 1);
       const bool valid = rb * FR + rl < A.Q;
@@ -494,7 +582,7 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
         float q[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          q[c] = lane < FR ? tbt[rl * 25 + 3 + c] + A.lds * tx[rl * F_LDO + 3 + c] : tbt[FR * 25 + rl * 25 + 3 + c];
+          q[c] = lane < FR ? tbt[rl * 25 + 3 + c] + A.lds * xcur[rl * OP + 3 + c] : tbt[FR * 25 + rl * 25 + 3 + c];
         if (!valid) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; }
         q2e(q, e);
       }
@@ -505,12 +593,12 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
         float p[25], tgv[25], g[25];
 #pragma unroll
         for (int r = 0; r < 25; ++r) {
-          p[r] = tbt[lane * 25 + r] + (r < 19 ? A.lds : 1.f) * tx[lane * F_LDO + r];
+          p[r] = tbt[lane * 25 + r] + (r < 19 ? A.lds : 1.f) * xcur[lane * OP + r];
           tgv[r] = tbt[FR * 25 + lane * 25 + r];
         }
         loss_part += loss_row_angles(p, tgv, e, eo, A.lw, g);
 #pragma unroll
-        for (int r = 0; r < 25; ++r) tx[lane * F_LDO + r] = (r < 19 ? A.lds : 1.f) * g[r];
+        for (int r = 0; r < 25; ++r) xcur[lane * OP + r] = (r < 19 ? A.lds : 1.f) * g[r];
       }
       fsync();
     }
@@ -520,27 +608,69 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
       const int rl = lane % FR, part = lane / FR;
       const int64_t row = rb * FR + rl;
       if (row < A.Q) {
-        const f4* src = reinterpret_cast<const f4*>(tx + rl * F_LDO) + part * NV;
         f4* dst = reinterpret_cast<f4*>((with_loss ? A.ldout : A.out) + row * F_LDX) + part * NV;
+        if constexpr (WLDS) {  // pitch 25: scalar reads, columns 25 .. 31 are zero
 #pragma unroll
-        for (int c = 0; c < NV; ++c) dst[c] = src[c];
+          for (int c = 0; c < NV; ++c) {
+            f4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int u = 4 * (part * NV + c) + e;
+              v[e] = u < 25 ? xcur[rl * OP + (u < 25 ? u : 0)] : 0.f;
+            }
+            dst[c] = v;
+          }
+        } else {
+          const f4* src = reinterpret_cast<const f4*>(tx + rl * F_LDO) + part * NV;
+#pragma unroll
+          for (int c = 0; c < NV; ++c) dst[c] = src[c];
+        }
       }
     }
     fsync();
     FSTAMP(9);  // gradient rows stored
-#ifdef KR_FUSED_STAMPS
-    fst[11] += 1;
-#endif
+    if constexpr (WLDS) xcur = xcur == tx ? tx + FR * F_LDX : tx;
   }
-#ifdef KR_FUSED_STAMPS
-  fst[10] = __builtin_amdgcn_s_memtime() - fkernel0;
-#endif
-  FSTAMP_OUT(0, blockIdx.x);
+
+  FSTAMP_OUT(0, part);
   if (with_loss) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) loss_part += __shfl_xor(loss_part, m, 64);
-    if (lane == 0) A.lpart[blockIdx.x] = loss_part;
+    if (lane == 0) A.lpart[part] = loss_part;
   }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A) {
+  __shared__ __attribute__((aligned(16))) float tx[FR * F_LDO];
+  __shared__ __attribute__((aligned(16))) float tbt[2 * FR * 25];  // fused loss: base rows, target rows of the block
+  fwd_rows<ACT, false>(A, tx, tbt, nullptr, threadIdx.x, blockIdx.x, gridDim.x, blockIdx.x);
+}
+
+extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+template <int ACT>
+__global__ __launch_bounds__(64 * FW3, 1) void mlp_fwd3_kernel(const FusedArgs A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const wl = wg_lds;
+  {
+    const int t = threadIdx.x;
+    const f4* s0 = reinterpret_cast<const f4*>(A.wf[0]);
+    const f4* s1 = reinterpret_cast<const f4*>(A.wf[1]);
+    const f4* s2 = reinterpret_cast<const f4*>(A.wf[2]);
+    f4* d = reinterpret_cast<f4*>(wl);
+    for (int i = t; i < FW3_W1 / 4; i += 64 * FW3) d[FW3_W0 / 4 + i] = s0[i];
+    for (int i = t; i < (FW3_W2 - FW3_W1) / 4; i += 64 * FW3) d[FW3_W1 / 4 + i] = s1[i];
+    for (int i = t; i < (FW3_B - FW3_W2) / 4; i += 64 * FW3) d[FW3_W2 / 4 + i] = s2[i];
+    if (t < 160) {  // compact biases out of the bias fragments: b[u] sits at fragment slot ((u / 16) 4 + u % 4) 64 + 16 ((u % 16) / 4)
+      const int k = t < 64 ? 0 : t < 128 ? 1 : 2, u = t - 64 * k;
+      wl[FW3_B + t] = A.bfr[k][((u >> 4) * 4 + (u & 3)) * 64 + 16 * ((u & 15) >> 2)];
+    }
+  }
+  __syncthreads();
+  float* const tx = wg_lds + FW3_FRAG + wv * FW3_WAVE;
+  float* const tbt = tx + 2 * FR * F_LDX;
+  const int gid = blockIdx.x * FW3 + wv;
+  fwd_rows<ACT, true>(A, tx, tbt, wl, lane, gid, (int64_t)gridDim.x * FW3, gid);
 }
 
 // sum of the per-workgroup loss partials of a fused forward + loss launch, added to *loss
@@ -669,7 +799,7 @@ __device__ __forceinline__ void wgrad_T(f4 (&acc)[NO][NI], const float* ta, cons
 constexpr int WPB = 4;
 constexpr int B3A_LDS = (32 + 64 + 64) * TP;  // floats per wavefront: dOUT^T, A1, A2 -> dZ2
 constexpr int B3B_LDS = (32 + 64) * TP;       // X^T, A1 -> dZ1
-extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+constexpr int B3B_WT = 4 * 16 * 64;           // W2^T fragments (floats), once per workgroup behind the wavefronts' tiles
 
 // acc (NA x NI and NB x NI accumulator tiles, two per-lane scalars) <- sum over the WPB wavefronts of the workgroup; the
 // result is valid in wavefront 0.  R: the workgroup's LDS (free once every wavefront is past its last row block).
@@ -782,6 +912,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3b_kernel(const FusedArgs 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* const ts = wg_lds + wv * B3B_LDS;  // X^T
   float* const tu = ts + 32 * TP;           // A1 -> dZ1
+  // W2^T fragments (4 tiles x 16 k-steps x 64 lanes: 16 KB) live in the LDS, one copy per workgroup: fetched from memory
+  // inside the products they sat in the wavefront's in-order load queue behind the row block's own loads
+  float* const wl = wg_lds + WPB * B3B_LDS;
+  {
+    const f4* src = reinterpret_cast<const f4*>(A.wt[1]);
+    f4* dst = reinterpret_cast<f4*>(wl);
+    for (int i = threadIdx.x; i < B3B_WT / 4; i += 64 * WPB) dst[i] = src[i];
+  }
+  __syncthreads();
   const int64_t nblk = (A.Q + FR - 1) / FR;
   const int64_t wave0 = (int64_t)blockIdx.x * WPB + wv, nwaves = (int64_t)gridDim.x * WPB;
   f4 aW1[4][2];
@@ -805,7 +944,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3b_kernel(const FusedArgs 
     FSTAMP(1);
     FChunk d1;
     chunk_zero(d1);
-    facc<4, 16>(d1.a, A.wt[1], A.kst[1], 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
+    facc<4, 16>(d1.a, wl, 16, 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
     fsync();
     FSTAMP(2);
     chunk_mul_grad_T<ACT>(d1, tu, lane);
@@ -1171,14 +1310,28 @@ int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_
     A.a1d = wsf;
     A.a2d = wsf + (size_t)nblk * 4 * FT * 64 * 4;
   }
-  launch_by_act(acts[0], [&](auto act) {
-    hipLaunchKernelGGL((mlp_fwd_fused_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
-  });
+  int nparts = grid;
+  int lrc = KR_OK;
+  if (n_layers == 3 && dims[3] <= 25) {
+    const int wgs = (int)((nblk + FW3 - 1) / FW3 < 256 ? (nblk + FW3 - 1) / FW3 : 256);  // one workgroup per CU
+    nparts = wgs * FW3;
+    launch_by_act(acts[0], [&](auto act) {
+      constexpr int a = decltype(act)::value;
+      const size_t lb = sizeof(float) * (FW3_FRAG + FW3 * FW3_WAVE);
+      if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_fwd3_kernel<a>), lb))) return;
+      hipLaunchKernelGGL((mlp_fwd3_kernel<a>), dim3(wgs), dim3(64 * FW3), lb, s, A);
+    });
+  } else {
+    launch_by_act(acts[0], [&](auto act) {
+      hipLaunchKernelGGL((mlp_fwd_fused_kernel<decltype(act)::value>), dim3(grid), dim3(64), 0, s, A);
+    });
+  }
+  if (lrc) return lrc;
   KR_HIP(hipGetLastError());
   if (fl && n_partials) {
-    *n_partials = grid;  // the caller's next kernel adds them up (train_tail_kernel)
+    *n_partials = nparts;  // the caller's next kernel adds them up (train_tail_kernel)
   } else if (fl) {
-    hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, A.lpart, grid, fl->loss);
+    hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, A.lpart, nparts, fl->loss);
     KR_HIP(hipGetLastError());
   }
   return KR_OK;
@@ -1222,7 +1375,7 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
     int lrc = KR_OK;
     launch_by_act(acts[0], [&](auto act) {
       constexpr int a = decltype(act)::value;
-      const size_t la = sizeof(float) * WPB * B3A_LDS, lb = sizeof(float) * WPB * B3B_LDS;
+      const size_t la = sizeof(float) * WPB * B3A_LDS, lb = sizeof(float) * (WPB * B3B_LDS + B3B_WT);
       if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_bwd3a_kernel<a>), la))) return;
       if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_bwd3b_kernel<a>), lb))) return;
       hipLaunchKernelGGL((mlp_bwd3a_kernel<a>), dim3(grid3), dim3(64 * WPB), la, s, A);

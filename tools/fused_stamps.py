@@ -30,7 +30,7 @@ d = np.zeros(48); d[0:12] = raw[0].sum(0); d[16:28] = raw[1].sum(0); d[32:44] = 
 nblk = (tr.Q + 31) // 32
 names = {
     "forward": (0, ["wait x rows", "bias 1", "layer 1 products", "act 1 + dump + bias 2", "layer 2 products", "act 2 + dump", "layer 3 products",
-                    "outputs -> tile", "loss epilogue", "store rows"]),
+                    "outputs -> tile", "loss epilogue", "store rows", "(loop head: wait for x)", "(request next x)"]),
     "bwd3a": (16, ["stage dOUT^T", "A1, A2 -> tiles", "dW3 += dOUT^T A2", "d2 = W3^T dOUT", "act' + dump dZ2 + dZ2 -> tile", "dW2 += dZ2^T A1"]),
     "bwd3b": (32, ["stage X^T", "dZ2, A1 (-> tile)", "d1 = W2^T dZ2", "act' + dZ1 -> tile", "dW1 += dZ1^T X"]),
 }
@@ -39,4 +39,3 @@ for k, (base, ph) in names.items():
     print(f"{k}: {tot / nblk:9.0f} cycles per row block of one wavefront ({nblk} blocks)")
     for i, p in enumerate(ph):
         print(f"    {p:34s} {d[base + i] / nblk:9.0f}  {100 * d[base + i] / tot:5.1f} %")
-print("forward: whole-kernel ticks per wavefront: mean", raw[0][:, 10].mean(), "max", raw[0][:, 10].max(), "blocks counted", d[11])

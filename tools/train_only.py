@@ -10,7 +10,7 @@ from cosserat_ode_torch import CosseratRodTorch
 from knode import setup_robot, simulate_batch
 from krod_train import KnodeTrainer
 dev = "cuda:0"
-M, T, N, kp, layers = 1024, 64, 100, [22, 67, 99], [64, 64]
+M, T, N, kp, layers = int(os.environ.get("KR_TRAIN_M", "1024")), 64, 100, [22, 67, 99], [64, 64]
 if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
     M, T, N, kp, layers = 512, 30, 100, [33, 55, 77, 99], [512]
 r = CosseratRod(use_fsolve=True); setup_robot(r); r.N = N; r.compute_intermediate_terms()
