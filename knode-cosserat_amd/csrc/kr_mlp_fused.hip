@@ -804,7 +804,8 @@ __device__ __forceinline__ void wgrad_T(f4 (&acc)[NO][NI], const float* ta, cons
 // (two rounds of a tree) and leave the workgroup as ONE slab - a quarter of the slab bytes written here and read by the
 // reduction (2048 slabs x 30 KB = 63 MB each way per epoch before).
 constexpr int WPB = 4;
-constexpr int B3A_LDS = (32 + 64 + 64) * TP;  // floats per wavefront: dOUT^T, A1, A2 -> dZ2
+constexpr int B3A_LDS = (64 + 64) * TP;       // floats per wavefront: [dOUT^T, later A1], A2 -> dZ2
+constexpr int B3A_WT = 4 * 8 * 64;            // W3^T fragments (floats), once per workgroup behind the tiles
 constexpr int B3B_LDS = (32 + 64) * TP;       // X^T, A1 -> dZ1
 constexpr int B3B_WT = 4 * 16 * 64;           // W2^T fragments (floats), once per workgroup behind the wavefronts' tiles
 
@@ -853,9 +854,18 @@ __device__ __forceinline__ void wg_tree_sum(f4 (&a)[NA][NI], f4 (&b)[NB][NI2], f
 template <int ACT>
 __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3a_kernel(const FusedArgs A) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // dOUT^T is dead once its B operands are in registers, A1 is needed last: they share a tile (A1 waits in registers until
+  // then), which makes room for the W3^T fragments - one copy per workgroup, as in the other kernels
   float* const ts = wg_lds + wv * B3A_LDS;  // dOUT^T
-  float* const tu = ts + 32 * TP;           // A1
+  float* const tu = ts;                     // A1 (after dOUT^T)
   float* const tv = tu + 64 * TP;           // A2 -> dZ2
+  float* const wl = wg_lds + WPB * B3A_LDS;
+  {
+    const f4* src = reinterpret_cast<const f4*>(A.wt[2]);
+    f4* dst = reinterpret_cast<f4*>(wl);
+    for (int i = threadIdx.x; i < B3A_WT / 4; i += 64 * WPB) dst[i] = src[i];
+  }
+  __syncthreads();
   const int64_t nblk = (A.Q + FR - 1) / FR;
   const int64_t wave0 = (int64_t)blockIdx.x * WPB + wv, nwaves = (int64_t)gridDim.x * WPB;
   f4 aW2[4][4], aW3[2][4];
@@ -873,11 +883,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3a_kernel(const FusedArgs 
   for (int64_t rb = wave0; rb < nblk; rb += nwaves) {
     stage_rows_T(A.dout, rb * FR, A.Q, ts, lane);
     FSTAMP(0);
+    FChunk h1;
     {
       FChunk h;
-      chunk_undump(h, A.a1d, rb, lane);
-      chunk_to_T(tu, h, lane);  // A1
       chunk_undump(h, A.a2d, rb, lane);
+      chunk_undump(h1, A.a1d, rb, lane);
       chunk_to_T(tv, h, lane);  // A2
     }
     fsync();
@@ -890,7 +900,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void mlp_bwd3a_kernel(const FusedArgs 
     {
       float bd[FT][8];
       load_bops_T(bd, ts, lane);
-      facc<4, 8>(d2.a, A.wt[2], A.kst[2], 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
+      fsync();
+      chunk_to_T(tu, h1, lane);  // A1 over dOUT^T
+      facc<4, 8>(d2.a, wl, 8, 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
     }
     FSTAMP(3);
     chunk_mul_grad_T<ACT>(d2, tv, lane);
@@ -1416,7 +1428,7 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
     int lrc = KR_OK;
     launch_by_act(acts[0], [&](auto act) {
       constexpr int a = decltype(act)::value;
-      const size_t la = sizeof(float) * WPB * B3A_LDS, lb = sizeof(float) * (WPB * B3B_LDS + B3B_WT);
+      const size_t la = sizeof(float) * (WPB * B3A_LDS + B3A_WT), lb = sizeof(float) * (WPB * B3B_LDS + B3B_WT);
       if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_bwd3a_kernel<a>), la))) return;
       if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_bwd3b_kernel<a>), lb))) return;
       hipLaunchKernelGGL((mlp_bwd3a_kernel<a>), dim3(grid3), dim3(64 * WPB), la, s, A);
