@@ -124,6 +124,8 @@ for dt in (torch.float64, torch.float32):
     ctl = torch.as_tensor(orc.batch_sine_controls(1024, TS, rr.del_t, 1235), device=dev).to(dt).contiguous()
     st = h.new_state(1024, dt, n_slots=3); h.init_straight(st[0]); Gs = torch.zeros((1024, 6), dtype=dt, device=dev)
     status = torch.zeros((1024, TS), dtype=torch.int32, device=dev)
+    h.simulate(ctl, st, Gs, ring=True, use_nn=True, status=status)   # (first call of this instantiation: code load)
+    st = h.new_state(1024, dt, n_slots=3); h.init_straight(st[0]); Gs.zero_()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     h.simulate(ctl, st, Gs, ring=True, use_nn=True, status=status)
     torch.cuda.synchronize(); el = (time.perf_counter() - t0) / TS

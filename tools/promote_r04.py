@@ -48,8 +48,8 @@ for p in ("f64", "f32"):
     out[f"simulate_nn_{p}"] = rec
 for cfg in ("cfg3", "cfg4"):
     st = os.path.join(G, f"{tag}_train_{cfg}_stats.csv")
-    rec = {"what": f"tools/train_only.py {cfg}: 20 fused training epochs (forward, loss, backward passes, slab reduction, Adam + clamp)"}
-    if os.path.exists(st): rec["kernel_stats"] = stats_rows(st, ("mlp_", "loss", "adam", "pack_", "reduce_"))
+    rec = {"what": f"tools/train_only.py {cfg}: 20 training epochs through kr_train_epoch (forward + loss, backward pass(es), one tail launch: slab and loss sums, Adam + clamp + plateau schedule, fragment update)"}
+    if os.path.exists(st): rec["kernel_stats"] = stats_rows(st, ("mlp_", "loss", "adam", "pack_", "reduce_", "tail"))
     for k in ("mlp_bwd3a", "mlp_bwd3b", "mlp_bwd2", "mlp_fwd"):
         c = counters(f"{tag}_train_{cfg}_sq", k)
         if c:
