@@ -640,6 +640,174 @@ __device__ __forceinline__ void fwd_rows(const FusedArgs& A, float* tx, float* t
   }
 }
 
+extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+// Two-layer networks in -> H1 -> out with H1 <= 512: ALL forward fragments in the LDS, one copy per CU (workgroups of FW2
+// wavefronts, one per CU): stamps of the kernel below on 28 -> 512 -> 25 showed, per hidden chunk, 1.1 k cycles waiting for
+// the bias fragments, 3.3 k for the 2.0 k of layer-1 products and 4.4 k for the 2.0 k of layer-2 products - fragments
+// from memory, each behind the previous in the wavefront's in-order return path.  With 128 KB of fragments there is no LDS
+// left for x / base / target tiles: the B operands of layer 1 are read from memory in operand layout (16 dwords per
+// lane), and base and target rows pass through the output tile one after the other (3.2 KB per wavefront).
+constexpr int FW2 = 8;
+constexpr int FW2_OUT = FR * 25;
+template <int ACT>
+__global__ __launch_bounds__(64 * FW2) void mlp_fwd2_kernel(const FusedArgs A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c1 = A.c1;
+  float* const wl0 = wg_lds;
+  float* const wl1 = wl0 + c1 * 2048;
+  float* const bl1 = wl1 + c1 * 2048;
+  float* const bl2 = bl1 + 64 * c1;
+  float* const to = bl2 + 32 + wv * FW2_OUT;
+  {
+    const int t = threadIdx.x;
+    const f4* s0 = reinterpret_cast<const f4*>(A.wf[0]);
+    const f4* s1 = reinterpret_cast<const f4*>(A.wf[1]);
+    f4* d0 = reinterpret_cast<f4*>(wl0);
+    f4* d1 = reinterpret_cast<f4*>(wl1);
+    for (int i = t; i < c1 * 512; i += 64 * FW2) { d0[i] = s0[i]; d1[i] = s1[i]; }
+    for (int u = t; u < 64 * c1; u += 64 * FW2) bl1[u] = A.bfr[0][((u >> 4) * 4 + (u & 3)) * 64 + 16 * ((u & 15) >> 2)];
+    if (t < 32) bl2[t] = A.bfr[1][((t >> 4) * 4 + (t & 3)) * 64 + 16 * ((t & 15) >> 2)];
+  }
+  __syncthreads();
+  const int64_t nblk = (A.Q + FR - 1) / FR;
+  const bool with_loss = A.lbase != nullptr;
+  const int gid = blockIdx.x * FW2 + wv;
+  const int c = lane & 15, g = lane >> 4;
+  float loss_part = 0.f;
+  for (int64_t rb = gid; rb < nblk; rb += (int64_t)gridDim.x * FW2) {
+    float bin[FT][8];
+#pragma unroll
+    for (int s = 0; s < FT; ++s) {
+      const int64_t row = rb * FR + 16 * s + c;
+      const float* xr = A.x + (row < A.Q ? row : A.Q - 1) * F_LDX + g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = xr[4 * k];
+        bin[s][k] = row < A.Q ? v : 0.f;
+      }
+    }
+    constexpr int LNV = (FR * 25 / 4 + 63) / 64;
+    f4 lvb[LNV], lvt[LNV];
+    if (with_loss) {
+      const int64_t e0 = rb * FR * 25, eN = A.Q * 25;
+      const f4* sb = reinterpret_cast<const f4*>(A.lbase + e0);
+      const f4* st = reinterpret_cast<const f4*>(A.ltarget + e0);
+#pragma unroll
+      for (int q = 0; q < LNV; ++q) {
+        const int i = lane + 64 * q;
+        lvb[q] = f4{0.f, 0.f, 0.f, 0.f};
+        lvt[q] = f4{1.f, 0.f, 0.f, 0.f};
+        if (i < FR * 25 / 4) {
+          if (e0 + 4 * i + 3 < eN) {
+            lvb[q] = sb[i];
+            lvt[q] = st[i];
+          } else {
+            for (int cc = 0; cc < 4; ++cc)
+              if (e0 + 4 * i + cc < eN) { lvb[q][cc] = A.lbase[e0 + 4 * i + cc]; lvt[q][cc] = A.ltarget[e0 + 4 * i + cc]; }
+          }
+        }
+      }
+    }
+    f4 oacc[2][FT];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const f4 b = *reinterpret_cast<const f4*>(bl2 + 16 * o + 4 * g);
+#pragma unroll
+      for (int s = 0; s < FT; ++s) oacc[o][s] = b;
+    }
+    for (int ch = 0; ch < c1; ++ch) {
+      FChunk h;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const f4 b = *reinterpret_cast<const f4*>(bl1 + 64 * ch + 16 * o + 4 * g);
+#pragma unroll
+        for (int s = 0; s < FT; ++s) h.a[o][s] = b;
+      }
+      facc<4, 8>(h.a, wl0, 8, 4 * ch, 0, lane, [&](int s, int k) { return bin[s][k]; });
+      chunk_act_only<ACT>(h);
+      facc<2, 16>(oacc, wl1, 16 * c1, 0, 16 * ch, lane, [&](int s, int k) { return h.a[k >> 2][s][k & 3]; });
+    }
+    // outputs -> tile [row][25]
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int s = 0; s < FT; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * o + 4 * g + r;
+          if (u < 25 && u < A.nout) to[(16 * s + c) * 25 + u] = oacc[o][s][r];
+          else if (u < 25) to[(16 * s + c) * 25 + u] = 0.f;
+        }
+    fsync();
+    if (with_loss) {
+      // as in fwd_rows: lane r owns row r, lane FR + r converts the target quaternion of row r; the base rows and then
+      // the target rows take the place of the outputs in the tile
+      static_assert(FR == 32, "lane <-> row map of the loss epilogue");
+      const int rl = lane & (FR - 1);
+      const bool valid = rb * FR + rl < A.Q, lower = lane < FR;
+      float p[25], tgv[25], gr[25];
+#pragma unroll
+      for (int r = 0; r < 25; ++r) p[r] = to[rl * 25 + r];
+      fsync();
+#pragma unroll
+      for (int q = 0; q < LNV; ++q)
+        if (lane + 64 * q < FR * 25 / 4) reinterpret_cast<f4*>(to)[lane + 64 * q] = lvb[q];
+      fsync();
+#pragma unroll
+      for (int r = 0; r < 25; ++r) p[r] = to[rl * 25 + r] + (r < 19 ? A.lds : 1.f) * p[r];
+      fsync();
+#pragma unroll
+      for (int q = 0; q < LNV; ++q)
+        if (lane + 64 * q < FR * 25 / 4) reinterpret_cast<f4*>(to)[lane + 64 * q] = lvt[q];
+      fsync();
+#pragma unroll
+      for (int r = 0; r < 25; ++r) tgv[r] = to[rl * 25 + r];
+      float e[3] = {0.f, 0.f, 0.f};
+      {
+        float q[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) q[cc] = lower ? p[3 + cc] : tgv[3 + cc];
+        if (!valid) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; }
+        q2e(q, e);
+      }
+      float eo[3];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) eo[cc] = __shfl_xor(e[cc], FR, 64);
+      fsync();
+      if (lower && valid) {
+        loss_part += loss_row_angles(p, tgv, e, eo, A.lw, gr);
+#pragma unroll
+        for (int r = 0; r < 25; ++r) to[lane * 25 + r] = (r < 19 ? A.lds : 1.f) * gr[r];
+      }
+      fsync();
+    }
+    {
+      constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;
+      const int rl = lane % FR, part = lane / FR;
+      const int64_t row = rb * FR + rl;
+      if (row < A.Q) {
+        f4* dst = reinterpret_cast<f4*>((with_loss ? A.ldout : A.out) + row * F_LDX) + part * NV;
+#pragma unroll
+        for (int cc = 0; cc < NV; ++cc) {
+          f4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int u = 4 * (part * NV + cc) + e;
+            v[e] = u < 25 ? to[rl * 25 + (u < 25 ? u : 0)] : 0.f;
+          }
+          dst[cc] = v;
+        }
+      }
+    }
+    fsync();
+  }
+  if (with_loss) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) loss_part += __shfl_xor(loss_part, m, 64);
+    if (lane == 0) A.lpart[gid] = loss_part;
+  }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A) {
   __shared__ __attribute__((aligned(16))) float tx[FR * F_LDO];
@@ -647,7 +815,6 @@ __global__ __launch_bounds__(64, 2) void mlp_fwd_fused_kernel(const FusedArgs A)
   fwd_rows<ACT, false>(A, tx, tbt, nullptr, threadIdx.x, blockIdx.x, gridDim.x, blockIdx.x);
 }
 
-extern __shared__ __attribute__((aligned(16))) float wg_lds[];
 template <int ACT>
 __global__ __launch_bounds__(64 * FW3, 1) void mlp_fwd3_kernel(const FusedArgs A) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1373,6 +1540,15 @@ int fused_mlp_forward(int64_t Q, int n_layers, const int32_t* dims, const int32_
       const size_t lb = sizeof(float) * (FW3_FRAG + FW3 * FW3_WAVE);
       if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_fwd3_kernel<a>), lb))) return;
       hipLaunchKernelGGL((mlp_fwd3_kernel<a>), dim3(wgs), dim3(64 * FW3), lb, s, A);
+    });
+  } else if (n_layers == 2 && A.c1 <= 8 && dims[2] <= 25) {
+    const int wgs = (int)((nblk + FW2 - 1) / FW2 < 256 ? (nblk + FW2 - 1) / FW2 : 256);
+    nparts = wgs * FW2;
+    launch_by_act(acts[0], [&](auto act) {
+      constexpr int a = decltype(act)::value;
+      const size_t lb = sizeof(float) * ((size_t)A.c1 * (4096 + 64) + 32 + FW2 * FW2_OUT);
+      if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_fwd2_kernel<a>), lb))) return;
+      hipLaunchKernelGGL((mlp_fwd2_kernel<a>), dim3(wgs), dim3(64 * FW2), lb, s, A);
     });
   } else {
     launch_by_act(acts[0], [&](auto act) {
