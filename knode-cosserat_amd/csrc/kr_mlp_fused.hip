@@ -29,6 +29,7 @@
 // torch parameters that change every optimizer step; ~30 KB).
 // Shapes served: in(<=32) -> H1 -> out(<=32) with any H1 and in -> H1 -> H2 -> out with H1, H2 <= 64; one activation
 // for all hidden layers.  Other networks use the generic GEMM path of kr_train.hip.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kr_internal.hpp"
@@ -978,10 +979,10 @@ constexpr int B3B_WT = 4 * 16 * 64;           // W2^T fragments (floats), once p
 
 // acc (NA x NI and NB x NI accumulator tiles, two per-lane scalars) <- sum over the WPB wavefronts of the workgroup; the
 // result is valid in wavefront 0.  R: the workgroup's LDS (free once every wavefront is past its last row block).
-template <int NA, int NB, int NI, int NI2>
+template <int W = WPB, int NA, int NB, int NI, int NI2>
 __device__ __forceinline__ void wg_tree_sum(f4 (&a)[NA][NI], f4 (&b)[NB][NI2], float& s0, float& s1, float* lds, int w,
                                             int lane) {
-  static_assert(WPB == 4, "two rounds");
+  static_assert(W >= 2 && W <= 16, "up to four rounds");
   constexpr int NF = NA * NI + NB * NI2 + 1;
   f4* R = reinterpret_cast<f4*>(lds);
   auto put = [&](f4* dst) {
@@ -1008,14 +1009,109 @@ __device__ __forceinline__ void wg_tree_sum(f4 (&a)[NA][NI], f4 (&b)[NB][NI2], f
     s0 += t[0];
     s1 += t[1];
   };
+  // round with stride st: wavefront (2 k + 1) st hands its sums to wavefront 2 k st through region k
+#pragma unroll
+  for (int st = 1; st < W; st *= 2) {
+    __syncthreads();
+    if ((w & (2 * st - 1)) == st) put(R + (w / (2 * st)) * NF * 64);
+    __syncthreads();
+    if ((w & (2 * st - 1)) == 0 && w + st < W) add(R + (w / (2 * st)) * NF * 64);
+  }
+}
+
+// ---- three-layer backward in ONE pass (kr_train_epoch) -------------------------------------------------------------------
+// Both passes below on the same row block back to back: dZ2 stays in registers (it is the B operand of W2^T dZ2 as it
+// stands), A1 stays in its tile - no dZ2 images through memory (99 MB per cfg3 epoch), one launch less.  The three
+// accumulator sets (128 registers) fit since the fragments moved to the LDS; 8 wavefronts per workgroup, one per CU:
+// 8 x 16 KB of tiles (dOUT^T / A1 / dZ1 share one, A2 / dZ2 / X^T the other) + W3^T + W2^T = 152 KB.
+constexpr int BW3 = 8;
+constexpr int BW3_LDS = (64 + 64) * TP;
+template <int ACT>
+__global__ __launch_bounds__(64 * BW3) void mlp_bwd3_kernel(const FusedArgs A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const tu = wg_lds + wv * BW3_LDS;  // dOUT^T, then A1, then dZ1
+  float* const tv = tu + 64 * TP;           // A2, then dZ2, then X^T
+  float* const wl3 = wg_lds + BW3 * BW3_LDS;  // W3^T fragments: 4 x 8 x 64
+  float* const wl2 = wl3 + B3A_WT;            // W2^T fragments: 4 x 16 x 64
+  {
+    const f4* s3 = reinterpret_cast<const f4*>(A.wt[2]);
+    const f4* s2 = reinterpret_cast<const f4*>(A.wt[1]);
+    f4* d3 = reinterpret_cast<f4*>(wl3);
+    f4* d2 = reinterpret_cast<f4*>(wl2);
+    for (int i = threadIdx.x; i < B3A_WT / 4; i += 64 * BW3) d3[i] = s3[i];
+    for (int i = threadIdx.x; i < B3B_WT / 4; i += 64 * BW3) d2[i] = s2[i];
+  }
   __syncthreads();
-  if (w & 1) put(R + (w >> 1) * NF * 64);
-  __syncthreads();
-  if (!(w & 1)) add(R + (w >> 1) * NF * 64);
-  __syncthreads();
-  if (w == 2) put(R);
-  __syncthreads();
-  if (w == 0) add(R);
+  const int64_t nblk = (A.Q + FR - 1) / FR;
+  const int64_t wave0 = (int64_t)blockIdx.x * BW3 + wv, nwaves = (int64_t)gridDim.x * BW3;
+  f4 aW1[4][2], aW2[4][4], aW3[2][4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aW1[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aW2[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aW3[o][i] = f4{0.f, 0.f, 0.f, 0.f};
+  float pb1 = 0.f, pb2 = 0.f, pbo = 0.f;
+  for (int64_t rb = wave0; rb < nblk; rb += nwaves) {
+    stage_rows_T(A.dout, rb * FR, A.Q, tu, lane);
+    FChunk d2;
+    {
+      FChunk h1;
+      {
+        FChunk h;
+        chunk_undump(h, A.a2d, rb, lane);
+        chunk_undump(h1, A.a1d, rb, lane);
+        chunk_to_T(tv, h, lane);  // A2
+      }
+      fsync();
+      if (lane < 32) pbo += row_sum_T(tu, lane);
+      wgrad_T<2, 4>(aW3, tu, tv, lane);  // dW3 += dOUT^T A2
+      chunk_zero(d2);
+      float bd[FT][8];
+      load_bops_T(bd, tu, lane);
+      fsync();
+      chunk_to_T(tu, h1, lane);  // A1 over dOUT^T
+      facc<4, 8>(d2.a, wl3, 8, 0, 0, lane, [&](int s, int k) { return bd[s][k]; });
+    }
+    chunk_mul_grad_T<ACT>(d2, tv, lane);
+    fsync();
+    chunk_to_T(tv, d2, lane);  // dZ2 (A2 is consumed)
+    fsync();
+    pb2 += row_sum_T(tv, lane);
+    wgrad_T<4, 4>(aW2, tv, tu, lane);  // dW2 += dZ2^T A1
+    fsync();
+    // ---- what used to be the second pass
+    stage_rows_T(A.x, rb * FR, A.Q, tv, lane);  // X^T over dZ2 (its first 32 rows)
+    FChunk d1;
+    chunk_zero(d1);
+    facc<4, 16>(d1.a, wl2, 16, 0, 0, lane, [&](int s, int k) { return d2.a[k >> 2][s][k & 3]; });
+    chunk_mul_grad_T<ACT>(d1, tu, lane);
+    fsync();
+    chunk_to_T(tu, d1, lane);  // dZ1 (A1 is consumed)
+    fsync();
+    pb1 += row_sum_T(tu, lane);
+    wgrad_T<4, 2>(aW1, tu, tv, lane);  // dW1 += dZ1^T X
+    fsync();
+  }
+  wg_tree_sum<BW3>(aW2, aW3, pb2, pbo, wg_lds, wv, lane);
+  {
+    f4 none[1][1] = {{f4{0.f, 0.f, 0.f, 0.f}}};
+    float unused = 0.f;
+    wg_tree_sum<BW3>(aW1, none, pb1, unused, wg_lds, wv, lane);
+  }
+  if (wv != 0) return;
+  float* slab = A.slab + (size_t)blockIdx.x * A.P;
+  wgrad_flush<2, 4>(aW3, slab + A.poff[4], A.nout, A.h2, 0, 0, lane);
+  wgrad_flush<4, 4>(aW2, slab + A.poff[2], A.h2, A.h1, 0, 0, lane);
+  wgrad_flush<4, 2>(aW1, slab + A.poff[0], A.h1, A.in, 0, 0, lane);
+  if (lane < A.h1) slab[A.poff[1] + lane] = pb1;
+  if (lane < A.h2) slab[A.poff[3] + lane] = pb2;
+  if (lane < A.nout) slab[A.poff[5] + lane] = pbo;
 }
 
 template <int ACT>
@@ -1430,6 +1526,10 @@ __global__ __launch_bounds__(TAIL_T) void train_tail_kernel(const TailArgs T) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
+static bool merged_bwd3() {
+  static const bool on = [] { const char* e = getenv("KR_BWD3_MERGED"); return !e || atoi(e) != 0; }();
+  return on;
+}
 bool fused_mlp_supported(int n_layers, const int32_t* dims, const int32_t* acts, int in_pad) {
   if (n_layers != 2 && n_layers != 3) return false;
   if (in_pad != 32 || dims[0] > 32 || dims[n_layers] > 32 || dims[n_layers] < 1) return false;
@@ -1602,6 +1702,16 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
     const int grid3 = (waves3 + WPB - 1) / WPB;  // wavefronts beyond the row blocks only take part in the sum
     A.nslab = grid3;
     int lrc = KR_OK;
+    if (leave && merged_bwd3()) {  // kr_train_epoch: both passes in one launch, one workgroup per CU
+      const int wgs = (int)((nblk + BW3 - 1) / BW3 < 256 ? (nblk + BW3 - 1) / BW3 : 256);
+      A.nslab = wgs;
+      launch_by_act(acts[0], [&](auto act) {
+        constexpr int a = decltype(act)::value;
+        const size_t lm = sizeof(float) * (BW3 * BW3_LDS + B3A_WT + B3B_WT);
+        if ((lrc = dyn_lds(reinterpret_cast<const void*>(&mlp_bwd3_kernel<a>), lm))) return;
+        hipLaunchKernelGGL((mlp_bwd3_kernel<a>), dim3(wgs), dim3(64 * BW3), lm, s, A);
+      });
+    } else
     launch_by_act(acts[0], [&](auto act) {
       constexpr int a = decltype(act)::value;
       const size_t la = sizeof(float) * (WPB * B3A_LDS + B3A_WT), lb = sizeof(float) * (WPB * B3B_LDS + B3B_WT);
