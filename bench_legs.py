@@ -248,11 +248,11 @@ def train_leg(torch, dev_index, M, T, N, key_pts, layers, ctl_seed=1236, epochs=
         "us_per_epoch_min": round(us[0], 2), "us_per_epoch_max": round(us[-1], 2), "wall_us_per_epoch": round(wall * 1e6, 2),
         "rows": tr.Q, "network": "->".join(map(str, sizes)), "trajectories": M, "window_steps": T - 1, "key_points": list(map(int, key_pts)),
         "N": N, "dtype": "f32",
-        "kernel": ("kr_train_epoch: " + ("kr::mlp_fwd3_kernel (+ loss epilogue), kr::mlp_bwd3a_kernel, kr::mlp_bwd3b_kernel"
-                                        if len(layers) == 2 else "kr::mlp_fwd_fused_kernel (+ loss epilogue), kr::mlp_bwd2_kernel")
+        "kernel": ("kr_train_epoch: " + ("kr::mlp_fwd3_kernel (+ loss epilogue), kr::mlp_bwd3_kernel"
+                                        if len(layers) == 2 else "kr::mlp_fwd2_kernel (+ loss epilogue), kr::mlp_bwd2_kernel")
                    + ", kr::train_tail_kernel (slab + loss sums, Adam, clamp, plateau schedule, fragment update)")
                   if tr.fused_epoch else "kr::mlp_fwd_fused_kernel (+ loss epilogue), kr::mlp_bwd*, kr::adam_plateau_kernel",
-        "launches_per_epoch": (4 if len(layers) == 2 else 3) if tr.fused_epoch else None,
+        "launches_per_epoch": 3 if tr.fused_epoch else None,
         "data_unconverged": bad, "loss_first": losses[0], "loss_last": losses[-1],
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(tf / FP32_PEAK_TF, 5),

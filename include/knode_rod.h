@@ -352,8 +352,8 @@ int kr_adam_plateau_step(kr_handle* h, int64_t n, float* params, float* grads, f
 
 /* ONE EPOCH of the one-step-ahead training loop on one rank - the body of physics_train.py:283-304 / :388-401 for the
  * epoch's whole data set: prediction of every scored row from the MLP, the four-term loss, loss.backward() restricted to
- * the MLP, optimizer.step() (Adam), scheduler.step(total_loss) (ReduceLROnPlateau), the weight clamp - as 3 (two-layer
- * network) or 4 (three-layer) kernel launches and no host round trip.  It is kr_mlp_forward_loss + kr_mlp_backward +
+ * the MLP, optimizer.step() (Adam), scheduler.step(total_loss) (ReduceLROnPlateau), the weight clamp - as 3 kernel launches
+ * (forward + loss, backward, optimizer tail) and no host round trip.  It is kr_mlp_forward_loss + kr_mlp_backward +
  * kr_adam_plateau_step with the glue between them removed: the loss partials and the per-workgroup gradient slabs are
  * added up inside the optimizer launch (fixed order, no atomics: an epoch is reproducible bit for bit), and that launch
  * also writes every updated parameter into the MFMA fragment buffers of `ws`, so the next epoch starts without a packing

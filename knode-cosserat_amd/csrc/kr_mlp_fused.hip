@@ -11,18 +11,18 @@
 //             dW3 += dOUT A2^T, dW2 += dZ2 A1^T, dW1 += dZ1 X^T                   (contractions over the samples of
 //             a block: both operands go through transposed LDS tiles T[unit][position], see "backward" below)
 //
-// Kernels (all __launch_bounds__(64, 2): two wavefronts per SIMD, so that the matrix-pipe phases of one overlap
-// the vector / LDS phases of the other):
-//   mlp_fwd_fused_kernel   all layers in registers; three-layer networks also dump A1 and A2 of every row block as raw
-//                          register images ([block][unit tile][sample tile][lane] x 16 B: coalesced, and already the
-//                          operand layout of the consumer)
-//   mlp_bwd3a_kernel       three layers, pass 1: dW3, db3, dZ2 (dumped the same way), from dOUT and the A2 image
-//   mlp_bwd3b_kernel       pass 2: dW2, db2, dZ1, dW1, db1 from the dZ2 and A1 images and X
+// Kernels (two wavefronts per SIMD, so that the matrix-pipe phases of one overlap the vector / LDS phases of the other):
+//   mlp_fwd3_kernel        three layers (H1, H2 <= 64, <= 25 outputs): 8 wavefronts per workgroup, fragments in the LDS, the
+//                          next block's x rows by LDS-direct loads; dumps A1 and A2 of every row block as raw register images
+//   mlp_fwd2_kernel        two layers with H1 <= 512: all fragments in the LDS of the CU
+//   mlp_fwd_fused_kernel   every other served shape: fragments from memory
+//   mlp_bwd3_kernel        three layers, the whole backward pass of a row block (kr_train_epoch); mlp_bwd3a / 3b_kernel: the
+//                          same in two launches with dZ2 through memory (kr_mlp_backward)
 //   mlp_bwd2_kernel        two layers (any hidden width, streamed in chunks of 64 units): recomputes the hidden chunk
-//   reduce_slabs_kernel    weight gradients accumulate in registers over all row blocks of a wave and leave it ONCE, as
-//                          plain stores into the wave's slab [wave][all parameters]; this kernel sums the slabs
-//                          (32 groups per parameter, one float atomic each).  Float atomics from ~1000 waves into the
-//                          same 10 k addresses serialised in L2 and cost more than the arithmetic (bwd3a 190 -> 59 us).
+//   train_tail_kernel      slab and loss sums, Adam, clamp, plateau schedule, fragment update (kr_train_epoch);
+//   reduce_slabs_kernel    the slab sum alone, with float atomics (kr_mlp_backward)
+// Weight gradients accumulate in registers over all row blocks of a wave, are added up over the wavefronts of the workgroup
+// through the LDS and leave it ONCE, as plain stores into the workgroup's slab [workgroup][all parameters].
 // Splitting the three-layer backward in two and dumping activations instead of recomputing them is what lets every
 // kernel fit 256 registers (2 waves per SIMD) without spilling; HBM is otherwise idle in these kernels.
 // Weights are re-packed into MFMA fragment order on the device at every call (pack_all_kernel, one launch; they are

@@ -285,7 +285,7 @@ class KnodeTrainer:
                         self.params[2 * k].clamp_(min=0)
 
     def _epoch_call(self, phase):
-        """kr_train_epoch: the epoch (phase 0) or its two halves around the all-reduce (1, 2) as 3-4 kernel launches."""
+        """kr_train_epoch: the epoch (phase 0) or its two halves around the all-reduce (1, 2) as 3 kernel launches."""
         h, sc = self.h, self.scheduler
         e = sc.steps
         if e >= self.loss_log.numel():
