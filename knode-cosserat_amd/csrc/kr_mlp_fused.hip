@@ -1411,6 +1411,17 @@ __global__ __launch_bounds__(TAIL_T) void train_tail_kernel(const TailArgs T) {
   __shared__ __attribute__((aligned(16))) float red[TAIL_G][64];
   __shared__ float lred[TAIL_T];
   const int tid = threadIdx.x, c0 = blockIdx.x * 64;
+  // the optimizer state of this workgroup's parameters is requested first, so that it travels with the slabs
+  float g_in = 0.f, p_in = 0.f, m_in = 0.f, v_in = 0.f, lo_in = 0.f;
+  if (tid < 64 && c0 + tid <= T.nparams) {
+    g_in = T.g[c0 + tid];
+    if (T.update && c0 + tid < T.nparams) {
+      p_in = T.p[c0 + tid];
+      m_in = T.m[c0 + tid];
+      v_in = T.v[c0 + tid];
+      if (T.lower) lo_in = T.lower[c0 + tid];
+    }
+  }
   {
     const int l16 = tid & 15, sg = tid >> 4;
     f4 a0 = f4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
@@ -1456,7 +1467,7 @@ __global__ __launch_bounds__(TAIL_T) void train_tail_kernel(const TailArgs T) {
   const int i = c0 + tid;
   if (i > T.nparams) return;
   if (i == T.nparams) {  // the loss slot
-    const float cur_f = T.g[i] + lsum;
+    const float cur_f = g_in + lsum;
     if (!T.update) {
       T.g[i] = cur_f;
       return;
@@ -1478,23 +1489,23 @@ __global__ __launch_bounds__(TAIL_T) void train_tail_kernel(const TailArgs T) {
     T.g[i] = 0.f;
     return;
   }
-  float gi = T.g[i];
+  float gi = g_in;
   if (T.nslab > 0) gi += (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   if (!T.update) {
     T.g[i] = gi;
     return;
   }
-  float pi = T.p[i];
+  float pi = p_in;
   {
     const float step_size = (float)(T.sched[T.parity] * (double)T.inv_bc1);
     if (T.wd != 0.f) gi = fmaf(T.wd, pi, gi);
-    const float mi = fmaf(T.b1, T.m[i], (1.f - T.b1) * gi);
-    const float vi = fmaf(T.b2, T.v[i], (1.f - T.b2) * gi * gi);
+    const float mi = fmaf(T.b1, m_in, (1.f - T.b1) * gi);
+    const float vi = fmaf(T.b2, v_in, (1.f - T.b2) * gi * gi);
     T.m[i] = mi;
     T.v[i] = vi;
     const float denom = sqrtf(vi) * T.inv_sqrt_bc2 + T.eps;
     pi -= step_size * (mi / denom);
-    if (T.lower) pi = fmaxf(pi, T.lower[i]);
+    if (T.lower) pi = fmaxf(pi, lo_in);
     T.p[i] = pi;
     T.g[i] = 0.f;
   }
