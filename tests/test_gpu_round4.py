@@ -5,6 +5,8 @@
   * a predictor image left by an MLP-off call is not loaded by an MLP-on call of the same batch size (its layout depends
     on the predictor's tap count);
   * ``iters`` of ``kr_step_batch`` counts the plain AND the damped phase on every step kernel (knode_rod.h)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -279,3 +281,14 @@ def test_train_epoch_argument_errors(torch_cuda):
     u = _epoch_trainer(torch, [96, 64])        # first hidden layer wider than the three-layer kernels serve
     u.step(sync_loss=False)
     assert u.fused_epoch is False and u.adam_step == 1
+
+
+def test_train_epoch_random_shapes(torch_cuda):
+    """tools/soak_epoch.py: twelve random (trajectories, window, key points, network, activation) draws - row counts from 6
+    to ~10^4 incl. fewer rows than a row block and fewer row blocks than a workgroup has wavefronts, hidden widths 8 .. 512 -
+    through kr_train_epoch and through the three separate calls: the same losses and parameters."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("soak_epoch", os.path.join(os.path.dirname(__file__), "..", "tools", "soak_epoch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(12, 11, verbose=False) == 0
