@@ -563,7 +563,11 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     for (int g = 0; g < MS_P - 1; ++g) updY1[g] = T(0);
     bool quick = false;
     float quick_est = 0.f;
-    if (!NN && S.quick_ok && small_prev && amp > 0.f) {  // (with the MLP on the ratio is not audited)
+#ifdef KR_QUICK_AUDIT
+    if (S.quick_ok && small_prev && amp > 0.f) {  // (audit build: the estimate is formed with the MLP on as well - tools/quick_audit_nn.py)
+#else
+    if (!NN && S.quick_ok && small_prev && amp > 0.f) {  // (with the MLP on a storing sweep has no cheaper form to gain from it: LABBOOK)
+#endif
       {
         T er[19];
         state_to_rows(y, er);
