@@ -245,7 +245,7 @@ static int simulate_impl(kr_handle* h, int64_t B, int64_t T_steps, int scheme, c
     sa.B = B; sa.T_steps = T_steps; sa.states = base; sa.slot_elems = (int64_t)slot; sa.ring = ring;
     sa.prev_init = (const T*)prev_init; sa.ctl = (const T*)ctl; sa.G = (T*)G; sa.tip = (T*)tip; sa.status = status;
     sa.tol = a0.tol; sa.tolA = a0.tolA; sa.fd_eps = a0.fd_eps; sa.hc1 = a0.hc1; sa.hc2 = a0.hc2;
-    sa.maxit = a0.maxit; sa.predictor = h->predictor; sa.residual_test = h->residual_test; sa.nn_lowp = h->nn_lowp_first;
+    sa.maxit = a0.maxit; sa.predictor = h->predictor; sa.residual_test = h->residual_test; sa.nn_lowp = h->nn_lowp_first; sa.nn_base_only = h->nn_base_only_store;
     sa.dbg = static_cast<unsigned long long*>(h->dbg);
     sa.pred_io = nullptr; sa.pred_load = 0;
     if (h->keep_predictor && (size_t)B * img_w * KR_PRED_IMG_DOUBLES * sizeof(double) <= ((size_t)1 << 30)) {
@@ -427,6 +427,7 @@ int kr_create(const kr_params* p, int device, kr_handle** out) {
   if (const char* e = std::getenv("KR_OVERLAP")) h->overlap = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_RESIDUAL_TEST")) h->residual_test = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_NN_LOWP_FIRST")) h->nn_lowp_first = std::atoi(e) ? 1 : 0;
+  if (const char* e = std::getenv("KR_NN_BASE_ONLY_STORE")) h->nn_base_only_store = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_MFMA_MLP")) h->mfma_mlp = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_FUSED_MLP")) h->fused_mlp = std::atoi(e) ? 1 : 0;
   *out = h;
@@ -464,6 +465,8 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
     h->overlap = value ? 1 : 0;
   } else if (n == "residual_test") {
     h->residual_test = value ? 1 : 0;
+  } else if (n == "nn_base_only_store") {
+    h->nn_base_only_store = value ? 1 : 0;
   } else if (n == "nn_lowp_first") {
     h->nn_lowp_first = value ? 1 : 0;
   } else {
@@ -492,6 +495,7 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   else if (n == "overlap") *value = h->overlap;
   else if (n == "residual_test") *value = h->residual_test;
   else if (n == "nn_lowp_first") *value = h->nn_lowp_first;
+  else if (n == "nn_base_only_store") *value = h->nn_base_only_store;
   else if (n == "last_overlap") *value = h->last_overlap;
   else {
     set_error("unknown option " + n);

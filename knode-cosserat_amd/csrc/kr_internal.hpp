@@ -101,6 +101,7 @@ struct kr_handle {
   int overlap = 1;           // ... and overlap the verifying sweep of step t with the Jacobian sweep of step t + 1 (kr_mso_impl.hpp)
   int last_overlap = 0;      // the last kr_simulate_batch ran the overlapped kernel
   int nn_lowp_first = 1;     // fp64, MLP on, persistent one-wavefront kernel: first sweep of a three-sweep step on the fp32 base chain
+  int nn_base_only_store = 1;  // fp64, MLP on, persistent one-wavefront kernel: storing sweeps without forward-difference columns
   void* resume_buf = nullptr;  // int32 per rod (SimArgs::resume)
   size_t resume_cap = 0;
   void* hist_ws = nullptr;     // history records [B][N][12] of the several-wavefront persistent kernel with the MLP on
@@ -215,6 +216,7 @@ struct SimArgs {
   int residual_test = 1;  // option "residual_test"
   T* hist_ws = nullptr;   // kr_msw_impl.hpp, MLP on: [B][N][12] history records (global memory instead of LDS)
   int nn_lowp = 1;        // option "nn_lowp_first" (MsSolveArgs::lowp_allowed)
+  int nn_base_only = 1;   // option "nn_base_only_store" (MsSolveArgs::bo_allowed)
 };
 
 // returns 1 when the persistent form does not apply

@@ -150,12 +150,15 @@ enum : int {
   CD_KSEI = 34, CD_KSEV = 43, CD_BSE = 46, CD_KBTI = 55, CD_BBT = 64, CD_SIZE = 76
 };
 // LDS elements of one rod (a multiple of 4, so every rod's slice stays 16-byte aligned)
+constexpr int MS_BO_PAD = 48;  // 304 (XB) + 48 (Tm) + 48 = 400 = 112 input-row + 288 hand-off elements
 constexpr int MS_BP_ELEMS = 3 * 3 * 19 + 1 + 12;  // [interval 1..3][p direction][19 rows], padding, [3][3] p updates (+3)
 template <typename T, int HS>
 __host__ __device__ inline size_t ms_lds_elems(int N, bool persist, bool nn = false) {
   // XB, Tm, Es are contiguous; with the MLP on the same region doubles as the 64 x 32 exchange
   // tile of mlp_mfma.hpp.  The cold table sits in front of XB so the tile cannot clobber it.
-  size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);
+  // (MS_BO_PAD: with the MLP on, XB + Tm + this pad hold the scratch of a BASE-ONLY network evaluation - 112 + 288 elements -
+  //  so that such a sweep leaves the forward-difference columns in Es alone: ms_newton, "base-only storing sweeps")
+  size_t alg = 2 * MS_YP * 8 + 48 + (nn ? MS_BO_PAD : 0) + ((WAVE * MS_YP + 3) & ~3);
   if (nn && alg < mj_scratch_elems<T>()) alg = mj_scratch_elems<T>();  // scratch of the base + JVP evaluator
   alg = (alg + 3) & ~size_t(3);
   size_t n = (size_t)N * HS + ((MS_P * MS_YP + 3) & ~3) + ((CD_SIZE + 3) & ~3) + 40 + alg;  // 40: Ti (6 x 6 inverse)
@@ -288,8 +291,8 @@ __device__ __forceinline__ MsLds<T> ms_carve(T* smem, int N, bool persist, bool 
   L.Ti = L.cold + ((CD_SIZE + 3) & ~3);
   L.XB = L.Ti + 40;
   L.Tm = L.XB + 2 * MS_YP * 8;
-  L.Es = L.Tm + 48;
-  size_t alg = 2 * MS_YP * 8 + 48 + ((WAVE * MS_YP + 3) & ~3);  // as in ms_lds_elems
+  L.Es = L.Tm + 48 + (nn ? MS_BO_PAD : 0);
+  size_t alg = 2 * MS_YP * 8 + 48 + (nn ? MS_BO_PAD : 0) + ((WAVE * MS_YP + 3) & ~3);  // as in ms_lds_elems
   if (nn && alg < mj_scratch_elems<T>()) alg = mj_scratch_elems<T>();
   L.c12 = persist ? L.XB + ((alg + 3) & ~size_t(3)) : nullptr;
   L.Bp = (persist && nn) ? L.c12 + (((size_t)N * 12 + 3) & ~size_t(3)) : nullptr;
@@ -317,6 +320,14 @@ struct MsSolveArgs {
   // previous step of the same rod: its first update d1 left 4 kappa d1^2 above the tolerance.  Storing sweeps - the only
   // ones acceptance is measured on - always run the fp64 chain.
   bool lowp_allowed = false, lowp_first = false;
+  // fp64 with the MLP on (option "nn_base_only_store"): BASE-ONLY STORING SWEEPS.  A storing sweep needs forward-difference
+  // columns only if it is not accepted; evaluated at the unperturbed inputs alone the network costs half (a sweep 231 k
+  // cycles instead of 378 k).  Such a sweep is judged like the MLP-off storing sweeps: residual test first (audited with
+  // the MLP on: tools/quick_audit_nn.py, update / estimate <= 46, factor 256), else a CHORD update through the factors of
+  // the last full sweep - its scratch lies on XB / Tm, so the columns in Es survive it -, accepted below half the
+  // tolerance and otherwise TAKEN as the iteration's update (there are no fresh columns to do better with); after two
+  // such sweeps in a row the next one is a full one again.
+  bool bo_allowed = false;
 };
 
 // Scaled maximum norm of the residual of a sweep - the interface jumps E_g - Y_{g+1} (19 rows each) and the tip
@@ -386,10 +397,14 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
   const int pslot = lane - (7 + 17 * (MS_P - 1));   // 0..5 on those lanes
   T* Bp = L.Bp;
 
+  int bo_run = 0;  // base-only sweeps since the last full one
   while (true) {
     // ---- role of the spare lanes in this sweep ------------------------------
     int iv_l = iv, s_l = R.s_i, len_l = R.len_i, pc = 0, pg = 0;
     SweepCtx<T, HS> Cl = C;
+    const bool bo = NN && S.bo_allowed && bo_run < 2 && storing && !flush && have_fac && dn_prev > T(0) && dn_prev <= T(1e-2);
+    if constexpr (NN) Cl.role.base_only = bo;
+    bo_run = bo ? bo_run + 1 : 0;
     if constexpr (PCOL) {
       const int rot = S.prot % 3;  // intervals served: (1, 2), (3, 1), (2, 3)
       const int ga = rot == 0 ? 1 : rot == 1 ? 3 : 2, gb = rot == 0 ? 2 : rot == 1 ? 1 : 3;
@@ -534,7 +549,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
     // (with the MLP on the factors in Es do not survive a sweep - the evaluator's scratch lies over them - so there is no
     //  chord check; the chord branch is only entered right after a full update, for the p columns)
     const bool small_prev = storing && have_fac && dn_prev > T(0) && dn_prev <= T(1e-2);
-    bool chord = !NN && small_prev;
+    bool chord = (!NN && small_prev) || bo;
     T d[6];
     T updY[MS_P - 1];
     T* dYb = XB;  // [g][19] scratch for dY_1 .. dY_{P-2} (p rows below)
@@ -566,7 +581,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
 #ifdef KR_QUICK_AUDIT
     if (S.quick_ok && small_prev && amp > 0.f) {  // (audit build: the estimate is formed with the MLP on as well - tools/quick_audit_nn.py)
 #else
-    if (!NN && S.quick_ok && small_prev && amp > 0.f) {  // (with the MLP on a storing sweep has no cheaper form to gain from it: LABBOOK)
+    if ((!NN || bo) && S.quick_ok && small_prev && amp > 0.f) {  // (with the MLP on: only on a base-only storing sweep)
 #endif
       {
         T er[19];
@@ -903,11 +918,11 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       }
       if (pcorr) break;  // (the second pass is a correction, not a chord check: nothing to be conclusive about)
     }
-    if (chord && !(finite && (T)dnf <= T(0.5) * S.tol)) {
+    if (chord && !bo && !(finite && (T)dnf <= T(0.5) * S.tol)) {
       chord = false;  // not conclusive: compute the Newton update proper
       continue;
     }
-    break;
+    break;  // (a base-only sweep has no columns of its own: its chord update is the update of this iteration)
     }
     const T dn = (T)dnf;
     if (res_full > 0.f && finite) amp = dnf / res_full;
@@ -935,7 +950,7 @@ __device__ __forceinline__ int ms_newton(const RodConst<T>& Pc, const MlpDev<T>&
       done = true;
       status = KR_ST_NONFINITE;
       flush = !storing;  // nothing consistent stored yet: stream the current iterate once
-    } else if (storing && dn <= S.tol) {
+    } else if (storing && dn <= (bo && !quick ? T(0.5) * S.tol : S.tol)) {  // (a chord update is conclusive below HALF the tolerance)
       done = true;  // the state streamed out by this sweep is the accepted one
       status = KR_ST_CONVERGED;
     } else {
@@ -1634,6 +1649,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   S.kappa = Q.kappa;
   S.quick_ok = A.residual_test != 0;
   S.lowp_allowed = NN && sizeof(T) == 8 && A.nn_lowp != 0 && M.f32_ok != 0;
+  S.bo_allowed = NN && sizeof(T) == 8 && A.nn_base_only != 0 && M.n_layers == 3 && M.otiles[1] == 4;
   S.lowp_first = true;  // (from the straight rod / a fresh call the first steps take three sweeps and more)
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;

@@ -241,6 +241,7 @@ struct NnRole {
   int xrow = -1;  // dx row of a lane with a column, when it is not 16 iv + col - 1 (p columns)
   int ptab = 0;   // wavefront-uniform: where the p columns' samples sit (mlp_jvp.hpp, jvp_scale_pack; 0: there are none)
   bool lowp = false;  // wavefront-uniform: fp64 sweep whose network evaluations may run the fp32 base chain (mlp_jvp_eval_lowp)
+  bool base_only = false;  // wavefront-uniform: a sweep that needs no forward-difference columns (mlp_jvp_eval_base)
 };
 // JVP_ONLY: the caller guarantees M.mfma_ok && M.jvp_ok and a lane role (kr_msw_impl.hpp with the MLP on) - no other
 // evaluator is compiled in, so that the register limit of a two-wavefronts-per-SIMD kernel holds for all its callees
@@ -259,9 +260,9 @@ __device__ __forceinline__ void nn_correct(const MlpDev<T>& M, T* bufA, T* bufB,
       x[25] = tf.x; x[26] = tf.y; x[27] = tf.z;
       T d[25];
       if constexpr (JVP_ONLY) {
-        mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d, role.xrow, role.ptab, role.lowp);
+        mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d, role.xrow, role.ptab, role.lowp, role.base_only);
       } else {
-        if (role.jvp && M.jvp_ok) mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d, role.xrow, role.ptab, role.lowp);  // wave-uniform choice
+        if (role.jvp && M.jvp_ok) mlp_jvp_eval<T, VAR>(M, x, tile, lane, role.iv, role.col, role.idle, role.zrow, d, role.xrow, role.ptab, role.lowp, role.base_only);  // wave-uniform choice
         else mlp_mfma_eval<T>(M, x, tile, lane, d);
       }
       T yr2[19];

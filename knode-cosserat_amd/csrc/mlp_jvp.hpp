@@ -191,14 +191,16 @@ __device__ __forceinline__ void chunk_operands(const double (&h)[4], double (&bv
   }
 }
 // activation of a chunk (4 values per lane, all of them real) and its act' to the table [interval j][unit]
-template <int ACT>
+template <int ACT, bool TABLE = true>
 __device__ __forceinline__ void chunk_activate(double (&h)[4], MJ_LDS float* actp, int lane) {
   // (fp64 also for fp32 sweeps: converting to float for a v_exp_f32 activation was measured SLOWER, 16.8 k against
   //  14.9 k cycles per evaluation in tools/ubench_jvp.hip)
   activate_block<double, ACT, 4>(h);
-  const int unit0 = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  if constexpr (TABLE) {
+    const int unit0 = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
-  for (int o = 0; o < 4; ++o) actp[(lane & 3) * 64 + 16 * o + unit0] = act_grad_from_value<ACT>((float)h[o]);
+    for (int o = 0; o < 4; ++o) actp[(lane & 3) * 64 + 16 * o + unit0] = act_grad_from_value<ACT>((float)h[o]);
+  }
 }
 
 // JVP: dst[o][s] += A(o, ks) * b[s][ks]  over KS k-steps of 32, NO unit tiles, 4 sample tiles
@@ -455,7 +457,9 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile(const fl
 // not_tail_called: a call site the optimiser marks `tail` (possible now that no argument lives in the caller's frame)
 // switches off LLVM's "no callee-saved registers" treatment of this internal function, and the callee then saves and
 // restores ~170 VGPRs through scratch memory on every evaluation.
-template <typename T, int ACT, int VAR = 0>
+// BO ("base only"): no JVP - the four unperturbed inputs alone (a storing sweep that is accepted by the residual test needs
+// no forward-difference columns: ms_newton, "base-only storing sweeps"); the J dx rows are not written.
+template <typename T, int ACT, int VAR = 0, bool BO = false>
 __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const float* wq0, const float* wq1, const float* wq2, const float* bq0,
                                                        const float* bq1, const float* bq2, const bf16x8* j0, const bf16x8* j1,
                                                        const bf16x8* j2, int kg1, int kg2, int ot0, int ot1, int jks1, int jks2,
@@ -530,10 +534,12 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
     f32x4 w1[2][4], w2[4][4];
     bf16x8 a1[1][4];
     base_load<4, 2>(w1, wq[0], 2, 0, 0, lane);
-    jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
     bf16x8 bdx[4];
+    if constexpr (!BO) {
+      jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bdx[s] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+      for (int s = 0; s < 4; ++s) bdx[s] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+    }
     double h1[4], h2[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) { h1[o] = (double)bq[0][o * 64 + lane]; h2[o] = (double)bq[1][o * 64 + lane]; }
@@ -544,7 +550,9 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
     // of a layer are 8 ds_read_b128 behind ONE wait, where the in-register route took 32 ds_swizzle and a wait per
     // k-step.  Rows are 18 doubles apart (bank spread).  The act' table goes through LDS anyway.
     constexpr int HOP_LD = 18;
-    MJ_LDS double* hop = (MJ_LDS double*)(dreg + 64 * MJ_DX_LD * 2);
+    // (BO: right behind the input rows - the whole scratch of a base-only evaluation is 112 + 288 elements, which the caller
+    //  places on XB / Tm so that Es survives: kr_ms_impl.hpp, MS_BO_PAD)
+    MJ_LDS double* hop = BO ? (MJ_LDS double*)(sbase + mj_xb_bytes<T>()) : (MJ_LDS double*)(dreg + 64 * MJ_DX_LD * 2);
     const int hop_w = ((lane & 3) * 4 + (lane >> 4)) * HOP_LD + ((lane >> 2) & 3);  // + 4 o: unit 16 o + 4 b + i = 4 (4 o + b) + i
     const MJ_LDS double* hop_r = hop + ((lane & 3) * 4 + (lane >> 4)) * HOP_LD;
     auto hand_off = [&](const double (&h)[4]) {
@@ -573,19 +581,21 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
     MJ_T3(2);
     // layer 1, JVP (16 products) under the activation of the base chain: the matrix pipe works while the vector ALU does
     bf16x8 a2[2][4];
-    jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
+    if constexpr (!BO) {
+      jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+      for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
-    chunk_activate<ACT>(h1, actp, lane);
+        for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
+    }
+    chunk_activate<ACT, !BO>(h1, actp, lane);
     hand_off(h1);
     MJ_T3(3);
     mj_wave_sync();
     double bv[16];
     operands(bv);
     bf16x8 b1[4][2];
-    jvp_scale_pack(dh, actp, lane, b1, ptab);
+    if constexpr (!BO) jvp_scale_pack(dh, actp, lane, b1, ptab);
     MJ_T3(4);
     // layer 2, base: 64 products; the first k-step of the JVP (16 products) between them
     zero_dh(dh);
@@ -595,8 +605,10 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int o = 0; o < 4; ++o) h2[o] = mfma4(MJ_W(w2[g][o], e), bv[4 * g + e], h2[o]);
+      if constexpr (!BO) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0][g], b1[s][0], dh[g][s], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0][g], b1[s][0], dh[g][s], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     MJ_T3(5);
@@ -604,18 +616,20 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
     f32x4 wo4[4][MM_OUT_T];
     bf16x8 ao[2][MM_OUT_T];
     base_load<MM_OUT_T, 4>(wo4, wq[2], kgs[2], 0, 0, lane);
-    jvp_load<MM_OUT_T, 2>(ao, jq[2], jkss[2], 0, 0, lane);
+    if constexpr (!BO) {
+      jvp_load<MM_OUT_T, 2>(ao, jq[2], jkss[2], 0, 0, lane);
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+      for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][o], b1[s][1], dh[o][s], 0, 0, 0);
-    chunk_activate<ACT>(h2, actp + 256, lane);
+        for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][o], b1[s][1], dh[o][s], 0, 0, 0);
+    }
+    chunk_activate<ACT, !BO>(h2, actp + 256, lane);
     hand_off(h2);
     MJ_T3(6);
     mj_wave_sync();
     operands(bv);
     bf16x8 b2[4][2];
-    jvp_scale_pack(dh, actp + 256, lane, b2, ptab);
+    if constexpr (!BO) jvp_scale_pack(dh, actp + 256, lane, b2, ptab);
     MJ_T3(7);
     // output layer: even / odd k-groups into separate partial sums; 4 JVP products behind each k-group
     {
@@ -626,9 +640,11 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int o2 = 0; o2 < MM_OUT_T; ++o2) a4[2 * (g & 1) + o2] = mfma4(MJ_W(wo4[g][o2], e), bv[4 * g + e], a4[2 * (g & 1) + o2]);
-        const int ks = g >> 1, o2 = g & 1;
+        if constexpr (!BO) {
+          const int ks = g >> 1, o2 = g & 1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ojvp[o2][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[ks][o2], b2[s][ks], ojvp[o2][s], 0, 0, 0);
+          for (int s = 0; s < 4; ++s) ojvp[o2][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[ks][o2], b2[s][ks], ojvp[o2][s], 0, 0, 0);
+        }
       }
       obase[0][0] = a4[0]; obase[1][0] = a4[1]; obase[0][1] = a4[2]; obase[1][1] = a4[3];
     }
@@ -640,12 +656,14 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
 #pragma unroll
   for (int o2 = 0; o2 < MM_OUT_T; ++o2)
     if (16 * o2 + dunit < 25) xb[j4 * MJ_XB_LD + 16 * o2 + dunit] = (T)(obase[o2][0] + obase[o2][1]);
+  if constexpr (!BO) {
 #pragma unroll
-  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+    for (int o2 = 0; o2 < MM_OUT_T; ++o2)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (16 * o2 + 4 * q < MJ_DOUT_LD)  // units 16 o2 + 4 q .. + 3 as one 16-byte store (28 .. 31 do not exist)
-        *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
+      for (int s = 0; s < 4; ++s)
+        if (16 * o2 + 4 * q < MJ_DOUT_LD)  // units 16 o2 + 4 q .. + 3 as one 16-byte store (28 .. 31 do not exist)
+          *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
+  }
   mj_wave_sync();
   MJ_T3(9);
 #ifdef MJ_STAMPS
@@ -924,12 +942,55 @@ __device__ __forceinline__ void mlp_jvp_eval_lowp(const MlpDev<double>& M, const
   mj_wave_sync();
 }
 
+// Base-only evaluation (fp64 sweeps, one-chunk three-layer networks): the network at the four unperturbed inputs; EVERY lane
+// gets the output of its interval's unperturbed lane (the perturbed trajectories of such a sweep are not used - they
+// only have to stay finite).  No dx rows, no JVP products, no J dx read-back: about half an evaluation.
+template <int VAR = 0>
+__device__ __forceinline__ void mlp_jvp_eval_base(const MlpDev<double>& M, const double (&x)[MM_IN], double* scratch, int lane,
+                                                  int iv, int col, bool idle, double (&out)[25], int ptab) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  double* xb = scratch;
+  if (col == 0 && !idle) {
+    d2* d = reinterpret_cast<d2*>(xb + iv * MJ_XB_LD);
+#pragma unroll
+    for (int k = 0; k < MM_IN / 2; ++k) d[k] = d2{x[2 * k], x[2 * k + 1]};
+  }
+  mj_wave_sync();
+#define MJ_B_ARGS                                                                                                           \
+  M.wq[0], M.wq[1], M.wq[2], M.bq[0], M.bq[1], M.bq[2], reinterpret_cast<const bf16x8*>(M.jfrag[0]),                         \
+      reinterpret_cast<const bf16x8*>(M.jfrag[1]), reinterpret_cast<const bf16x8*>(M.jfrag[2]), M.kgroups[1], M.kgroups[2],  \
+      M.otiles[0], M.otiles[1], M.jksteps[1], M.jksteps[2], M.n_layers, ptab, scratch, lane
+  switch (M.acts[0]) {
+    case KR_ACT_TANH: mlp_jvp_tile3<double, KR_ACT_TANH, VAR, true>(MJ_B_ARGS); break;
+    case KR_ACT_SOFTPLUS: mlp_jvp_tile3<double, KR_ACT_SOFTPLUS, VAR, true>(MJ_B_ARGS); break;
+    case KR_ACT_RELU: mlp_jvp_tile3<double, KR_ACT_RELU, VAR, true>(MJ_B_ARGS); break;
+    case KR_ACT_ELU: mlp_jvp_tile3<double, KR_ACT_ELU, VAR, true>(MJ_B_ARGS); break;
+    default: mlp_jvp_tile3<double, KR_ACT_NONE, VAR, true>(MJ_B_ARGS); break;
+  }
+#undef MJ_B_ARGS
+  {
+    const d2* b = reinterpret_cast<const d2*>(xb + iv * MJ_XB_LD);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const d2 v = b[k];
+      out[2 * k] = v[0];
+      if (2 * k + 1 < 25) out[2 * k + 1] = v[1];
+    }
+  }
+  mj_wave_sync();
+}
+
 template <typename T, int VAR = 0>
 __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
-                                             bool idle, int zrow, T (&out)[25], int xrow = -1, int ptab = 0, bool lowp = false) {
+                                             bool idle, int zrow, T (&out)[25], int xrow = -1, int ptab = 0, bool lowp = false,
+                                             bool base_only = false) {
   using V = typename MjVec<T>::type;
   constexpr int n = MjVec<T>::n;
   if constexpr (std::is_same<T, double>::value) {
+    if (__builtin_amdgcn_readfirstlane((int)base_only) && M.n_layers == 3 && M.otiles[1] == 4) {  // wave-uniform
+      mlp_jvp_eval_base<VAR>(M, x, scratch, lane, iv, col, idle, out, ptab);
+      return;
+    }
     if (__builtin_amdgcn_readfirstlane((int)lowp) && M.f32_ok) {  // wave-uniform
       mlp_jvp_eval_lowp<VAR>(M, x, scratch, lane, iv, col, idle, zrow, out, xrow, ptab);
       return;
