@@ -292,3 +292,39 @@ def test_train_epoch_random_shapes(torch_cuda):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(12, 11, verbose=False) == 0
+
+
+@pytest.mark.parametrize("act,scale", [("elu", 1.0), ("tanh", 1.5), ("relu", 2.0)])
+def test_base_only_storing_sweeps(torch_cuda, act, scale):
+    """MLP-on fp64 persistent kernel: storing sweeps evaluate the network at the unperturbed inputs only and are accepted by
+    the residual test or a chord update through the last full sweep's factors (option nn_base_only_store, default on).
+    Against the same run at a tolerance of 1e-11 the states are as close with the option on as with it off."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    N, B, T = 40, 96, 40
+    r = make_robot(None, N)
+    mlp = orc.make_mlp([28, 64, 64, 25], act, seed=5)
+    mlp.weights = [w * scale for w in mlp.weights]
+    inject(r, mlp)
+    h = r._native()
+    assert h.get_option("nn_base_only_store") == 1
+    dt = torch.float64
+    ctl = torch.as_tensor(orc.batch_sine_controls(B, T, r.del_t, 99), device=DEV).contiguous()
+
+    def run(on, tol=0.0, maxit=0):
+        h.set_option("nn_base_only_store", on)
+        st = h.new_state(B, dt, n_slots=T + 1)
+        h.init_straight(st[0])
+        G = torch.zeros((B, 6), dtype=dt, device=DEV)
+        status = torch.zeros((B, T), dtype=torch.int32, device=DEV)
+        h.simulate(ctl, st, G, ring=False, status=status, use_nn=True, tol=tol, maxit=maxit)
+        torch.cuda.synchronize()
+        assert h.get_option("last_sim_path") == 2 and int((status != 0).sum()) == 0
+        return st.cpu().numpy()[1:, :, :, :25]
+
+    ref = run(0, tol=1e-11, maxit=30)
+    den = np.sqrt((ref ** 2).sum(axis=(2, 3)))
+    err_on = (np.sqrt(((run(1) - ref) ** 2).sum(axis=(2, 3))) / den).max()
+    err_off = (np.sqrt(((run(0) - ref) ** 2).sum(axis=(2, 3))) / den).max()
+    h.set_option("nn_base_only_store", 1)
+    assert err_on < 5e-8 and err_on < 2.0 * max(err_off, 5e-9), (err_on, err_off)
