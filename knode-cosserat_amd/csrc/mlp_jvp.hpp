@@ -683,7 +683,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3(const f
 // units 4 b .. 4 b + 3 of sample j - contiguous, so activations, act' and the hand-off to the next layer are ONE 16-byte
 // LDS write each.  8 cycles per product (4 independent accumulators: one per k mod 4), 124 products.  The output layer
 // (25 -> 32 rows) uses the upper 8 blocks for the second half of its k range; the halves meet through ds_bpermute.
-template <int ACT, int VAR = 0>
+template <int ACT, int VAR = 0, bool BO = false>
 __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const float* w0, const float* w1p, const float* w2p,
                                                                           const float* b0, const float* b1p, const float* b2p,
                                                                           const bf16x8* j0, const bf16x8* j1, const bf16x8* j2,
@@ -705,7 +705,8 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
   const MJ_LDS bf16x8* dx = (const MJ_LDS bf16x8*)dreg;
   MJ_LDS float* dout = (MJ_LDS float*)dreg;
   constexpr int HOP_LD = 68;  // floats per sample row of the hand-off tile (bank spread of the four rows)
-  MJ_LDS float* hop = (MJ_LDS float*)(dreg + 64 * MJ_DX_LD * 2);
+  // (BO - base only, see mlp_jvp_tile3: the hand-off rows right behind the input rows, 112 + 272 elements in all)
+  MJ_LDS float* hop = BO ? (MJ_LDS float*)(sbase + mj_xb_bytes<T>()) : (MJ_LDS float*)(dreg + 64 * MJ_DX_LD * 2);
   const int q = lane >> 4, c = lane & 15, j4 = lane & 3, blk = lane >> 2;
   auto mfma1 = [](float a, float b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0); };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -714,14 +715,16 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
 #pragma unroll
   for (int g = 0; g < 7; ++g) W1[g] = wf[0][g * 64 + lane];
   bf16x8 a1[1][4];
-  jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
+  if constexpr (!BO) jvp_load<4, 1>(a1, jq[0], 1, 0, 0, lane);
   f32x4 acc[4] = {bf[0][blk], zero4, zero4, zero4};
   f32x4 xin[16];
 #pragma unroll
   for (int g = 0; g < 7; ++g) xin[g] = *reinterpret_cast<const MJ_LDS f32x4*>(xb + j4 * MJ_XB_LD + 4 * g);
   bf16x8 bdx[4];
+  if constexpr (!BO) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) bdx[s] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+    for (int s = 0; s < 4; ++s) bdx[s] = dx[(16 * s + c) * (MJ_DX_LD / 8) + q];
+  }
   f32x4 W2[16];
 #pragma unroll
   for (int g = 0; g < 16; ++g) W2[g] = wf[1][g * 64 + lane];
@@ -743,7 +746,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
     f32x4 a = {v[0], v[1], v[2], v[3]};
     f32x4 gr = {act_grad_from_value<ACT>(v[0]), act_grad_from_value<ACT>(v[1]), act_grad_from_value<ACT>(v[2]),
                 act_grad_from_value<ACT>(v[3])};
-    *reinterpret_cast<MJ_LDS f32x4*>(tab + j4 * 64 + 4 * blk) = gr;
+    if constexpr (!BO) *reinterpret_cast<MJ_LDS f32x4*>(tab + j4 * 64 + 4 * blk) = gr;
     *reinterpret_cast<MJ_LDS f32x4*>(hop + j4 * HOP_LD + 4 * blk) = a;
     h = a;
   };
@@ -754,7 +757,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = mfma1(W1[g][e], xin[g][e], acc[e]);
 #if MJ_VARIANT & 1
-    if (g < 4) {
+    if (!BO && g < 4) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) dh[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][g], bdx[s], dh[g][s], 0, 0, 0);
     }
@@ -764,13 +767,15 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
   MJ_T3(2);
   // layer 1, JVP (16 products) under the activation
   bf16x8 a2[2][4];
-  jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
+  if constexpr (!BO) {
+    jvp_load<4, 2>(a2, jq[1], 2, 0, 0, lane);
 #if !(MJ_VARIANT & 1)
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0][o], bdx[s], dh[o][s], 0, 0, 0);
 #endif
+  }
   f32x4 h = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   activate_hand_off(h, actp);
   MJ_T3(3);
@@ -778,7 +783,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
 #pragma unroll
   for (int g = 0; g < 16; ++g) xin[g] = *reinterpret_cast<const MJ_LDS f32x4*>(hop + j4 * HOP_LD + 4 * g);
   bf16x8 b1[4][2];
-  jvp_scale_pack(dh, actp, lane, b1, ptab);
+  if constexpr (!BO) jvp_scale_pack(dh, actp, lane, b1, ptab);
   MJ_T3(4);
   // layer 2, base: 64 products; the first k-step of the JVP (16 products) between them
   acc[0] = bias2; acc[1] = zero4; acc[2] = zero4; acc[3] = zero4;
@@ -790,7 +795,7 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
   for (int g = 0; g < 16; ++g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = mfma1(W2[g][e], xin[g][e], acc[e]);
-    if ((g & 3) == 3) {
+    if (!BO && (g & 3) == 3) {
       const int o = g >> 2;
 #pragma unroll
       for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0][o], b1[s][0], dh[o][s], 0, 0, 0);
@@ -803,12 +808,14 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
 #pragma unroll
   for (int g = 0; g < 8; ++g) Wo[g] = wf[2][g * 64 + lane];
   bf16x8 ao[2][MM_OUT_T];
-  jvp_load<MM_OUT_T, 2>(ao, jq[2], 2, 0, 0, lane);
   const f32x4 bias3 = bf[2][blk];
+  if constexpr (!BO) {
+    jvp_load<MM_OUT_T, 2>(ao, jq[2], 2, 0, 0, lane);
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][o], b1[s][1], dh[o][s], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) dh[o][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1][o], b1[s][1], dh[o][s], 0, 0, 0);
+  }
   h = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   activate_hand_off(h, actp + 256);
   MJ_T3(6);
@@ -818,14 +825,14 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
 #pragma unroll
   for (int g = 0; g < 8; ++g) xin[g] = *reinterpret_cast<const MJ_LDS f32x4*>(hop + j4 * HOP_LD + 32 * khalf + 4 * g);
   bf16x8 b2[4][2];
-  jvp_scale_pack(dh, actp + 256, lane, b2, ptab);
+  if constexpr (!BO) jvp_scale_pack(dh, actp + 256, lane, b2, ptab);
   MJ_T3(7);
   acc[0] = bias3; acc[1] = zero4; acc[2] = zero4; acc[3] = zero4;
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = mfma1(Wo[g][e], xin[g][e], acc[e]);
-    if (g & 1) {
+    if (!BO && (g & 1)) {
       const int ks = g >> 2, o2 = (g >> 1) & 1;
 #pragma unroll
       for (int s = 0; s < 4; ++s) ojvp[o2][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[ks][o2], b2[s][ks], ojvp[o2][s], 0, 0, 0);
@@ -847,12 +854,14 @@ __device__ __attribute__((noinline, not_tail_called)) void mlp_jvp_tile3f(const 
   }
   mj_wave_sync();
   if (lane < 28) *reinterpret_cast<MJ_LDS f32x4*>(xb + j4 * MJ_XB_LD + 4 * blk) = h;  // units 4 blk .. 4 blk + 3 < 28 (25 used)
+  if constexpr (!BO) {
 #pragma unroll
-  for (int o2 = 0; o2 < MM_OUT_T; ++o2)
+    for (int o2 = 0; o2 < MM_OUT_T; ++o2)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (16 * o2 + 4 * q < MJ_DOUT_LD)
-        *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
+      for (int s = 0; s < 4; ++s)
+        if (16 * o2 + 4 * q < MJ_DOUT_LD)
+          *reinterpret_cast<MJ_LDS f32x4*>(dout + (16 * s + c) * MJ_DOUT_LD + 16 * o2 + 4 * q) = ojvp[o2][s];
+  }
   mj_wave_sync();
   MJ_T3(9);
 #ifdef MJ_STAMPS
@@ -980,12 +989,53 @@ __device__ __forceinline__ void mlp_jvp_eval_base(const MlpDev<double>& M, const
   mj_wave_sync();
 }
 
+// the same for fp32 sweeps (fp32 base chain, mlp_jvp_tile3f)
+template <int VAR = 0>
+__device__ __forceinline__ void mlp_jvp_eval_base(const MlpDev<float>& M, const float (&x)[MM_IN], float* scratch, int lane,
+                                                  int iv, int col, bool idle, float (&out)[25], int ptab) {
+  float* xb = scratch;
+  if (col == 0 && !idle) {
+    f32x4* d = reinterpret_cast<f32x4*>(xb + iv * MJ_XB_LD);
+#pragma unroll
+    for (int k = 0; k < MM_IN / 4; ++k) d[k] = f32x4{x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]};
+  }
+  mj_wave_sync();
+#define MJ_B_ARGS                                                                                                    \
+  M.w32[0], M.w32[1], M.w32[2], M.b32[0], M.b32[1], M.b32[2], reinterpret_cast<const bf16x8*>(M.jfrag[0]),             \
+      reinterpret_cast<const bf16x8*>(M.jfrag[1]), reinterpret_cast<const bf16x8*>(M.jfrag[2]), ptab, scratch, lane
+  switch (M.acts[0]) {
+    case KR_ACT_TANH: mlp_jvp_tile3f<KR_ACT_TANH, VAR, true>(MJ_B_ARGS); break;
+    case KR_ACT_SOFTPLUS: mlp_jvp_tile3f<KR_ACT_SOFTPLUS, VAR, true>(MJ_B_ARGS); break;
+    case KR_ACT_RELU: mlp_jvp_tile3f<KR_ACT_RELU, VAR, true>(MJ_B_ARGS); break;
+    case KR_ACT_ELU: mlp_jvp_tile3f<KR_ACT_ELU, VAR, true>(MJ_B_ARGS); break;
+    default: mlp_jvp_tile3f<KR_ACT_NONE, VAR, true>(MJ_B_ARGS); break;
+  }
+#undef MJ_B_ARGS
+  {
+    const f32x4* b = reinterpret_cast<const f32x4*>(xb + iv * MJ_XB_LD);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const f32x4 v = b[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * k + e < 25) out[4 * k + e] = v[e];
+    }
+  }
+  mj_wave_sync();
+}
+
 template <typename T, int VAR = 0>
 __device__ __forceinline__ void mlp_jvp_eval(const MlpDev<T>& M, const T (&x)[MM_IN], T* scratch, int lane, int iv, int col,
                                              bool idle, int zrow, T (&out)[25], int xrow = -1, int ptab = 0, bool lowp = false,
                                              bool base_only = false) {
   using V = typename MjVec<T>::type;
   constexpr int n = MjVec<T>::n;
+  if constexpr (std::is_same<T, float>::value) {
+    if (__builtin_amdgcn_readfirstlane((int)base_only) && M.f32_ok) {  // wave-uniform
+      mlp_jvp_eval_base<VAR>(M, x, scratch, lane, iv, col, idle, out, ptab);
+      return;
+    }
+  }
   if constexpr (std::is_same<T, double>::value) {
     if (__builtin_amdgcn_readfirstlane((int)base_only) && M.n_layers == 3 && M.otiles[1] == 4) {  // wave-uniform
       mlp_jvp_eval_base<VAR>(M, x, scratch, lane, iv, col, idle, out, ptab);

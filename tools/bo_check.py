@@ -44,6 +44,18 @@ for name, B, N, T, mk in (("bench workload", 1024, 100, 120, lambda B, T, d: ben
             return float((np.sqrt(((x[1:] - ref[1:])[..., :25] ** 2).sum(axis=(2, 3))) / np.sqrt((ref[1:][..., :25] ** 2).sum(axis=(2, 3)))).max())
         (a, ba, ta, pa), (b, bb, tb, pb) = res
         print(f"   against a run at tol 1e-11 ({int((status != 0).sum())} unconverged): on {err(a):.2e}, off {err(b):.2e}")
+        # fp32 sweeps, both ways, against the same fp64 reference
+        ctl32 = ctl.float().contiguous()
+        e32 = []
+        for on in (1, 0):
+            h.set_option("nn_base_only_store", on)
+            for rep in range(2):
+                st32 = h.new_state(B, torch.float32, n_slots=T + 1); h.init_straight(st32[0]); G32 = torch.zeros((B, 6), dtype=torch.float32, device=dev)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                h.simulate(ctl32, st32, G32, ring=False, status=status, use_nn=True)
+                torch.cuda.synchronize(); el32 = (time.perf_counter() - t0) / T
+            e32.append((err(st32.double().cpu().numpy()), el32, int((status != 0).sum())))
+        print(f"   fp32 sweeps: on {e32[0][1]*1e3:.3f} ms/step err {e32[0][0]:.2e} ({e32[0][2]} unconverged), off {e32[1][1]*1e3:.3f} ms/step err {e32[1][0]:.2e} ({e32[1][2]} unconverged)")
         # per rod and step, over the whole state (slots 0..24 of every grid point)
         num = np.sqrt(((a[1:] - b[1:])[..., :25] ** 2).sum(axis=(2, 3)))
         den = np.sqrt((b[1:][..., :25] ** 2).sum(axis=(2, 3)))
