@@ -148,6 +148,16 @@ def forward_leg(torch, dev_index, B, N, T, warm, dtype, seed, mlp=None, full_tra
     tf = B * T * flops / best_ev / 1e12
     out["roofline"] = {"bound": bound, "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5),
                        "how": how}
+    if mlp is not None:
+        # NOT a utilisation: the nominal count prices 22 full evaluations of the network per grid point and sweep in the
+        # arithmetic type of the run, the kernel evaluates 4 rows that way and the perturbed columns as bf16 JVPs (and, on
+        # storing sweeps, the 4 rows only) - the ratio says how far the method is from the naive operation count
+        out["roofline"]["frac"] = None
+        out["roofline"]["nominal_over_vector_peak"] = round(tf / peak, 5)
+        out["roofline"]["note"] = ("nominal operation count (every forward-difference column a full network evaluation) over the "
+                                   "vector peak of the run's type - not a utilisation figure: the kernel runs the columns as bf16 JVPs "
+                                   "on the matrix cores; executed matrix / vector instruction counts: profiles/*_kernels.json "
+                                   "(simulate_nn_*: SQ_INSTS_MFMA, SQ_INSTS_VALU)")
     per_rod_step = (25 * N + 4) * esize if full_trajectory else (3 + 4) * esize
     gbs = B * T * per_rod_step / best_ev / 1e9
     out["roofline"]["hbm"] = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
