@@ -150,6 +150,14 @@ int kr_destroy(kr_handle* h);
  *                    most 39 x off over 8 workloads x 1024 rods x 300 steps - DESIGN.md section 4; the factor 256 is
  *                    the margin).  status still reports "converged"; with 0 every accepted sweep carries a measured
  *                    update (Newton, or chord within 1 %) below the tolerance, at ~5 % of the throughput.
+ *   "nn_base_only_store" 1 (default) / 0: MLP on, persistent one-wavefront kernel: a storing sweep that follows an update
+ *                    <= 1e-2 evaluates the network at the unperturbed inputs only (no forward-difference columns: half an
+ *                    evaluation) and is judged by the residual test above (audited with the MLP on: at most 46 x off) or,
+ *                    failing that, by a CHORD update through the factors of the last full sweep - accepted below HALF
+ *                    the tolerance, otherwise applied as the iteration's update; after two such sweeps the next one is
+ *                    full.  0: every sweep carries its columns (~15 % slower; tools/bo_check.py compares the two).
+ *   "nn_lowp_first"  1 (default) / 0: fp64 sweeps, MLP on: the FIRST sweep of a step whose predecessor needed two
+ *                    corrections evaluates the network's base chain in fp32 (the accepted state never comes from it).
  *   "overlap"        1 (default) / 0: persistent form only - verify step t on spare lanes of the Jacobian sweep of
  *                    step t + 1 (kr_mso_impl.hpp; Euler sweeps, MLP off, diagonal material matrices)
  *   "predictor"      0..8: how kr_simulate_batch may form the initial guess of each step (default 8;
