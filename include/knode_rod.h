@@ -25,7 +25,11 @@
  *    partials), so a call on another stream than the handle's previous call
  *    is made to wait for everything that call's stream had queued (an event,
  *    no host synchronisation) - calls on one handle never overlap on the
- *    device; use one handle per stream for concurrency.  The current HIP
+ *    device; use one handle per stream for concurrency.  LIFETIME: the
+ *    handle keeps the hipStream_t of its previous call to record that event
+ *    on; a stream must therefore stay alive until the handle's NEXT call has
+ *    returned (or the handle is destroyed) - destroy streams after the handle
+ *    has moved on, not between two of its calls.  The current HIP
  *    device of the calling thread must be the handle's (KR_E_ARG otherwise).
  *  - dtype selects the arithmetic type of the call: KR_F32 or KR_F64.  All
  *    floating-point array arguments of a call have that element type.
@@ -373,7 +377,10 @@ int kr_adam_plateau_step(kr_handle* h, int64_t n, float* params, float* grads, f
  *   phase 0: the whole epoch.  phase 1: everything up to the update - grads then holds the summed gradients and the loss,
  *   ready for a data-parallel all-reduce - and phase 2: the update from grads as they stand (after the all-reduce).
  *   repack != 0: the caller changed `params` since the last call (a loaded checkpoint): fragments are packed afresh.
- *   They are also packed whenever ws, params or the network differ from the handle's previous call.
+ *   They are also packed whenever ws, params or the network differ from the handle's previous call, and after any
+ *   kr_mlp_forward[_loss] / kr_adam[_plateau]_step on the same ws / params.  "Differ" is judged by ADDRESS: a ws or
+ *   params buffer that was freed and allocated again at the same address with other contents needs repack = 1 on its
+ *   first call (a trainer object passes it on its first epoch).
  * KR_E_UNSUPPORTED for networks the fused training kernels do not serve (use the three separate calls). */
 int kr_train_epoch(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* dims, const int32_t* acts, float* params,
                    float* grads, float* exp_avg, float* exp_avg_sq, const float* lower, double* sched, const float* x,

@@ -167,12 +167,7 @@ static void fill_consts(const kr_params& p, const kr_derived& d, RodConst<T>& c)
            is_diag(d.rhoJ);
 }
 
-static void free_mlp(kr_handle* h) {
-  for (void* p : h->mlp_allocs) (void)hipFree(p);
-  h->mlp_allocs.clear();
-  h->mlp_f = MlpDev<float>{};
-  h->mlp_d = MlpDev<double>{};
-}
+void free_mlp_plan(kr_handle* h);  // (below, beside kr_set_mlp)
 
 }  // namespace kr
 
@@ -512,7 +507,7 @@ int kr_debug_buffer(kr_handle* h, void* dev_ptr) {
 
 int kr_destroy(kr_handle* h) {
   if (!h) return KR_OK;
-  free_mlp(h);
+  free_mlp_plan(h);
   if (h->ws) (void)hipFree(h->ws);
   if (h->pred_buf) (void)hipFree(h->pred_buf);
   if (h->resume_buf) (void)hipFree(h->resume_buf);
@@ -548,68 +543,100 @@ int kr_mlp_eval_batch(kr_handle* h, int64_t Q, const void* x, void* out, int dty
                          : launch_mlp_eval<double>(h, Q, (const double*)x, (double*)out, s);
 }
 
-int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
-               const float* const* b, int src_on_device, void* stream) {
-  KR_CHECK_H(h);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (int rc_order_ = order_stream(h, s)) return rc_order_;
-  KR_HIP(hipStreamSynchronize(s));
-  free_mlp(h);
-  if (n_layers == 0) return KR_OK;
-  if (n_layers < 0 || n_layers > KR_MAX_LAYERS) {
-    set_error("n_layers out of range");
-    return KR_E_ARG;
+}  // extern "C"
+
+// kr_set_mlp packs ON THE DEVICE: per network SHAPE the host builds, once, a gather plan - for every element of every
+// packed buffer the (source array, offset) it comes from - and one launch of mlp_pack_kernel fills all of them from the
+// caller's weights.  The same shape again (evaluate() with live weights every 50 epochs, physics_train.py:136-167) costs
+// that one launch: no device-to-host copy, no hipMalloc, no host synchronisation.
+namespace kr {
+constexpr int PACK_MAX_JOBS = 112;  // 4 buffers per layer for KR_MAX_LAYERS layers + 9 per layer of the matrix-core forms (<= 3)
+constexpr uint32_t PACK_ZERO = 0xFFFFFFFFu;
+enum { PACK_F32 = 0, PACK_F64 = 1, PACK_BF16 = 2 };
+struct PackJobs {
+  int n;
+  uint32_t start[PACK_MAX_JOBS + 1];  // first element of job j in the concatenated index table
+  void* dst[PACK_MAX_JOBS];
+  uint8_t type[PACK_MAX_JOBS];
+  const float* src[2 * KR_MAX_LAYERS];  // W[0], b[0], W[1], b[1], ...
+};
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const PackJobs J, const uint32_t* __restrict__ idx) {
+  const uint32_t total = J.start[J.n];
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    int j = 0;
+    while (i >= J.start[j + 1]) ++j;
+    const uint32_t e = i - J.start[j], code = idx[i];
+    const float v = code == PACK_ZERO ? 0.f : J.src[code >> 27][code & 0x07FFFFFFu];
+    if (J.type[j] == PACK_F32) static_cast<float*>(J.dst[j])[e] = v;
+    else if (J.type[j] == PACK_F64) static_cast<double*>(J.dst[j])[e] = (double)v;
+    else {  // bf16, round to nearest even on the bits (what the host packing of earlier rounds did)
+      const uint32_t u = __float_as_uint(v);
+      static_cast<uint16_t*>(J.dst[j])[e] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
   }
-  KR_CHECK_PTR(dims); KR_CHECK_PTR(acts); KR_CHECK_PTR(W); KR_CHECK_PTR(b);
-  const int want_in = h->params.nn_input_history ? 53 : 28;
-  if (dims[0] != want_in || dims[n_layers] != 25) {
-    set_error("MLP must map " + std::to_string(want_in) + " -> 25 (cosserat_ode_torch.py:60-62)");
-    return KR_E_ARG;
-  }
-  MlpDev<float> mf{};
-  MlpDev<double> md{};
+}
+}  // namespace kr
+
+struct kr_mlp_plan {
+  uint64_t key = 0;
+  kr::MlpDev<float> mf{};
+  kr::MlpDev<double> md{};
+  kr::PackJobs jobs{};
+  uint32_t* idx = nullptr;    // device: source code of every destination element
+  unsigned char* arena = nullptr;  // device: every packed buffer
+  float* staging = nullptr;   // device copy of host-side sources (src_on_device = 0)
+  size_t src_off[2 * KR_MAX_LAYERS + 1] = {};
+};
+
+namespace kr {
+void free_mlp_plan(kr_handle* h) {
+  kr_mlp_plan* P = h->mlp_plan;
+  if (!P) return;
+  if (P->idx) (void)hipFree(P->idx);
+  if (P->arena) (void)hipFree(P->arena);
+  if (P->staging) (void)hipFree(P->staging);
+  delete P;
+  h->mlp_plan = nullptr;
+}
+
+// Builds the plan of one shape.  The layouts are those of mlp_lane.hpp (Wt, b), mlp_mfma.hpp (wfrag, bfrag), mlp_jvp.hpp
+// (wq, bq, jfrag, w32, b32); every buffer is described by the source code of each of its elements.
+static int build_mlp_plan(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* acts, kr_mlp_plan& P) {
+  MlpDev<float>& mf = P.mf;
+  MlpDev<double>& md = P.md;
+  mf = MlpDev<float>{};
+  md = MlpDev<double>{};
   mf.n_layers = md.n_layers = n_layers;
+  struct Job { std::vector<uint32_t> code; int type; const void** t0; const void** t1; };
+  std::vector<Job> jobs;
+  auto add = [&](std::vector<uint32_t>&& code, int type, const void** t0, const void** t1 = nullptr) {
+    jobs.push_back(Job{std::move(code), type, t0, t1});
+  };
   int maxd = dims[0];
-  for (int k = 0; k <= n_layers; ++k) {
-    if (dims[k] <= 0) { set_error("bad layer width"); return KR_E_ARG; }
-    mf.dims[k] = md.dims[k] = dims[k];
-  }
+  for (int k = 0; k <= n_layers; ++k) mf.dims[k] = md.dims[k] = dims[k];
+  P.src_off[0] = 0;
   for (int k = 0; k < n_layers; ++k) {
-    if (acts[k] < KR_ACT_NONE || acts[k] > KR_ACT_ELU) { set_error("bad activation code"); return KR_E_ARG; }
+    P.src_off[2 * k + 1] = P.src_off[2 * k] + (size_t)dims[k] * dims[k + 1];
+    P.src_off[2 * k + 2] = P.src_off[2 * k + 1] + (size_t)dims[k + 1];
+    if ((size_t)dims[k] * dims[k + 1] >= (1u << 27)) { set_error("layer too large"); return KR_E_ARG; }
+  }
+  auto wc = [](int k, size_t off) { return ((uint32_t)(2 * k) << 27) | (uint32_t)off; };
+  auto bc = [](int k, size_t off) { return ((uint32_t)(2 * k + 1) << 27) | (uint32_t)off; };
+  for (int k = 0; k < n_layers; ++k) {
     const int in = dims[k], out = dims[k + 1];
     const int opad = (out + 15) / 16 * 16;
     if (opad > maxd) maxd = opad;
     mf.out_pad[k] = md.out_pad[k] = opad;
     mf.acts[k] = md.acts[k] = acts[k];
-    std::vector<float> hw((size_t)in * out), hb(out);
-    if (src_on_device) {
-      KR_HIP(hipMemcpy(hw.data(), W[k], hw.size() * sizeof(float), hipMemcpyDeviceToHost));
-      KR_HIP(hipMemcpy(hb.data(), b[k], hb.size() * sizeof(float), hipMemcpyDeviceToHost));
-    } else {
-      std::memcpy(hw.data(), W[k], hw.size() * sizeof(float));
-      std::memcpy(hb.data(), b[k], hb.size() * sizeof(float));
-    }
-    std::vector<float> wt_f((size_t)in * opad, 0.f), b_f(opad, 0.f);
-    std::vector<double> wt_d((size_t)in * opad, 0.0), b_d(opad, 0.0);
+    std::vector<uint32_t> wt((size_t)in * opad, PACK_ZERO), bb(opad, PACK_ZERO);
     for (int o = 0; o < out; ++o) {
-      b_f[o] = hb[o];
-      b_d[o] = (double)hb[o];
-      for (int i = 0; i < in; ++i) {
-        wt_f[(size_t)i * opad + o] = hw[(size_t)o * in + i];
-        wt_d[(size_t)i * opad + o] = (double)hw[(size_t)o * in + i];
-      }
+      bb[o] = bc(k, o);
+      for (int i = 0; i < in; ++i) wt[(size_t)i * opad + o] = wc(k, (size_t)o * in + i);
     }
-    void *dwf, *dbf, *dwd, *dbd;
-    KR_HIP(hipMalloc(&dwf, wt_f.size() * sizeof(float)));  h->mlp_allocs.push_back(dwf);
-    KR_HIP(hipMalloc(&dbf, b_f.size() * sizeof(float)));   h->mlp_allocs.push_back(dbf);
-    KR_HIP(hipMalloc(&dwd, wt_d.size() * sizeof(double))); h->mlp_allocs.push_back(dwd);
-    KR_HIP(hipMalloc(&dbd, b_d.size() * sizeof(double)));  h->mlp_allocs.push_back(dbd);
-    KR_HIP(hipMemcpy(dwf, wt_f.data(), wt_f.size() * sizeof(float), hipMemcpyHostToDevice));
-    KR_HIP(hipMemcpy(dbf, b_f.data(), b_f.size() * sizeof(float), hipMemcpyHostToDevice));
-    KR_HIP(hipMemcpy(dwd, wt_d.data(), wt_d.size() * sizeof(double), hipMemcpyHostToDevice));
-    KR_HIP(hipMemcpy(dbd, b_d.data(), b_d.size() * sizeof(double), hipMemcpyHostToDevice));
-    mf.Wt[k] = static_cast<float*>(dwf);  mf.b[k] = static_cast<float*>(dbf);
-    md.Wt[k] = static_cast<double*>(dwd); md.b[k] = static_cast<double*>(dbd);
+    add(std::vector<uint32_t>(wt), PACK_F32, (const void**)&mf.Wt[k]);
+    add(std::vector<uint32_t>(bb), PACK_F32, (const void**)&mf.b[k]);
+    add(std::move(wt), PACK_F64, (const void**)&md.Wt[k]);
+    add(std::move(bb), PACK_F64, (const void**)&md.b[k]);
   }
   mf.max_dim = md.max_dim = maxd;
   // ---- matrix-core form (mlp_mfma.hpp) --------------------------------------------------------
@@ -623,16 +650,8 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
       const bool last = (k == n_layers - 1);
       const int tiles = last ? 2 : ((out + 63) / 64) * 4;
       const int ks = k == 0 ? 7 : prev_tiles * 4;
-      std::vector<float> hw((size_t)in * out), hb(out);
-      if (src_on_device) {
-        KR_HIP(hipMemcpy(hw.data(), W[k], hw.size() * sizeof(float), hipMemcpyDeviceToHost));
-        KR_HIP(hipMemcpy(hb.data(), b[k], hb.size() * sizeof(float), hipMemcpyDeviceToHost));
-      } else {
-        std::memcpy(hw.data(), W[k], hw.size() * sizeof(float));
-        std::memcpy(hb.data(), b[k], hb.size() * sizeof(float));
-      }
-      std::vector<float> wf_f((size_t)tiles * ks * 64), bf_f((size_t)tiles * 4 * 64);
-      std::vector<double> wf_d(wf_f.size()), bf_d(bf_f.size());
+      std::vector<uint32_t> wf_f((size_t)tiles * ks * 64, PACK_ZERO), bf_f((size_t)tiles * 4 * 64, PACK_ZERO);
+      std::vector<uint32_t> wf_d(wf_f.size(), PACK_ZERO), bf_d(bf_f.size(), PACK_ZERO);
       for (int t = 0; t < tiles; ++t)
         for (int lane = 0; lane < 64; ++lane) {
           const int uo = 16 * t + (lane & 15), q = lane >> 4;
@@ -642,51 +661,39 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
             const int ui_d = 4 * s2 + q;
             const int ui_f = k == 0 ? 4 * s2 + q : 16 * (s2 / 4) + 4 * q + (s2 % 4);
             const size_t o = ((size_t)t * ks + s2) * 64 + lane;
-            wf_d[o] = (uo < out && ui_d < in) ? (double)hw[(size_t)uo * in + ui_d] : 0.0;
-            wf_f[o] = (uo < out && ui_f < in) ? hw[(size_t)uo * in + ui_f] : 0.f;
+            if (uo < out && ui_d < in) wf_d[o] = wc(k, (size_t)uo * in + ui_d);
+            if (uo < out && ui_f < in) wf_f[o] = wc(k, (size_t)uo * in + ui_f);
           }
           for (int r = 0; r < 4; ++r) {
             const int row_d = 16 * t + q + 4 * r, row_f = 16 * t + 4 * q + r;
             const size_t o = ((size_t)t * 4 + r) * 64 + lane;
-            bf_d[o] = row_d < out ? (double)hb[row_d] : 0.0;
-            bf_f[o] = row_f < out ? hb[row_f] : 0.f;
+            if (row_d < out) bf_d[o] = bc(k, row_d);
+            if (row_f < out) bf_f[o] = bc(k, row_f);
           }
         }
-      void *pwf, *pbf, *pwd, *pbd;
-      KR_HIP(hipMalloc(&pwf, wf_f.size() * sizeof(float)));  h->mlp_allocs.push_back(pwf);
-      KR_HIP(hipMalloc(&pbf, bf_f.size() * sizeof(float)));  h->mlp_allocs.push_back(pbf);
-      KR_HIP(hipMalloc(&pwd, wf_d.size() * sizeof(double))); h->mlp_allocs.push_back(pwd);
-      KR_HIP(hipMalloc(&pbd, bf_d.size() * sizeof(double))); h->mlp_allocs.push_back(pbd);
-      KR_HIP(hipMemcpy(pwf, wf_f.data(), wf_f.size() * sizeof(float), hipMemcpyHostToDevice));
-      KR_HIP(hipMemcpy(pbf, bf_f.data(), bf_f.size() * sizeof(float), hipMemcpyHostToDevice));
-      KR_HIP(hipMemcpy(pwd, wf_d.data(), wf_d.size() * sizeof(double), hipMemcpyHostToDevice));
-      KR_HIP(hipMemcpy(pbd, bf_d.data(), bf_d.size() * sizeof(double), hipMemcpyHostToDevice));
-      mf.wfrag[k] = static_cast<float*>(pwf);  mf.bfrag[k] = static_cast<float*>(pbf);
-      md.wfrag[k] = static_cast<double*>(pwd); md.bfrag[k] = static_cast<double*>(pbd);
+      add(std::move(wf_f), PACK_F32, (const void**)&mf.wfrag[k]);
+      add(std::move(bf_f), PACK_F32, (const void**)&mf.bfrag[k]);
+      add(std::move(wf_d), PACK_F64, (const void**)&md.wfrag[k]);
+      add(std::move(bf_d), PACK_F64, (const void**)&md.bfrag[k]);
       mf.ksteps[k] = md.ksteps[k] = ks;
       mf.otiles[k] = md.otiles[k] = tiles;
       {
         // base chain of mlp_jvp.hpp: fp32 A fragments of v_mfma_f64_4x4x4_4b, four k-steps per 16-byte element
         const int kg = k == 0 ? 2 : prev_tiles;  // k-groups of 16 inputs (first layer: 28 -> 32)
-        std::vector<float> wq((size_t)tiles * kg * 64 * 4, 0.f), bq((size_t)tiles * 64, 0.f);
+        std::vector<uint32_t> wq((size_t)tiles * kg * 64 * 4, PACK_ZERO), bq((size_t)tiles * 64, PACK_ZERO);
         for (int t = 0; t < tiles; ++t)
           for (int lane = 0; lane < 64; ++lane) {
             const int uo = 16 * t + (lane & 15);
             for (int g = 0; g < kg; ++g)
               for (int e = 0; e < 4; ++e) {
                 const int ui = 4 * (4 * g + e) + (lane >> 4);
-                if (uo < out && ui < in) wq[(((size_t)t * kg + g) * 64 + lane) * 4 + e] = hw[(size_t)uo * in + ui];
+                if (uo < out && ui < in) wq[(((size_t)t * kg + g) * 64 + lane) * 4 + e] = wc(k, (size_t)uo * in + ui);
               }
             const int ub = 16 * t + 4 * ((lane >> 2) & 3) + (lane >> 4);  // unit of this lane in the D layout
-            if (ub < out) bq[(size_t)t * 64 + lane] = hb[ub];
+            if (ub < out) bq[(size_t)t * 64 + lane] = bc(k, ub);
           }
-        void *pw, *pb;
-        KR_HIP(hipMalloc(&pw, wq.size() * sizeof(float))); h->mlp_allocs.push_back(pw);
-        KR_HIP(hipMalloc(&pb, bq.size() * sizeof(float))); h->mlp_allocs.push_back(pb);
-        KR_HIP(hipMemcpy(pw, wq.data(), wq.size() * sizeof(float), hipMemcpyHostToDevice));
-        KR_HIP(hipMemcpy(pb, bq.data(), bq.size() * sizeof(float), hipMemcpyHostToDevice));
-        mf.wq[k] = md.wq[k] = static_cast<float*>(pw);
-        mf.bq[k] = md.bq[k] = static_cast<float*>(pb);
+        add(std::move(wq), PACK_F32, (const void**)&mf.wq[k], (const void**)&md.wq[k]);
+        add(std::move(bq), PACK_F32, (const void**)&mf.bq[k], (const void**)&md.bq[k]);
         mf.kgroups[k] = md.kgroups[k] = kg;
       }
       {
@@ -694,26 +701,17 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
         // two adjacent 16x16x32 accumulator tiles present: slot (q, j) of k-step s = unit 32 s + 4 q + j (j < 4),
         // 32 s + 16 + 4 q + j - 4 (j >= 4)
         const int jks = k == 0 ? 1 : prev_tiles / 2;
-        std::vector<uint16_t> jf((size_t)tiles * jks * 64 * 8);
-        auto bf16 = [](float f) {
-          uint32_t u;
-          std::memcpy(&u, &f, 4);
-          return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-        };
+        std::vector<uint32_t> jf((size_t)tiles * jks * 64 * 8, PACK_ZERO);
         for (int t = 0; t < tiles; ++t)
           for (int s2 = 0; s2 < jks; ++s2)
             for (int lane = 0; lane < 64; ++lane) {
               const int uo = 16 * t + (lane & 15), q = lane >> 4;
               for (int j = 0; j < 8; ++j) {
                 const int ui = k == 0 ? 8 * q + j : 32 * s2 + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
-                const float w = (uo < out && ui < in) ? hw[(size_t)uo * in + ui] : 0.f;
-                jf[(((size_t)t * jks + s2) * 64 + lane) * 8 + j] = bf16(w);
+                if (uo < out && ui < in) jf[(((size_t)t * jks + s2) * 64 + lane) * 8 + j] = wc(k, (size_t)uo * in + ui);
               }
             }
-        void* pj;
-        KR_HIP(hipMalloc(&pj, jf.size() * sizeof(uint16_t)));  h->mlp_allocs.push_back(pj);
-        KR_HIP(hipMemcpy(pj, jf.data(), jf.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        mf.jfrag[k] = md.jfrag[k] = pj;
+        add(std::move(jf), PACK_BF16, (const void**)&mf.jfrag[k], (const void**)&md.jfrag[k]);
         mf.jksteps[k] = md.jksteps[k] = jks;
       }
       prev_tiles = tiles;
@@ -725,15 +723,7 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
       const int groups[3] = {7, 16, 8};
       for (int k = 0; k < 3; ++k) {
         const int in = dims[k], out = dims[k + 1];
-        std::vector<float> hw((size_t)in * out), hb(out);
-        if (src_on_device) {
-          KR_HIP(hipMemcpy(hw.data(), W[k], hw.size() * sizeof(float), hipMemcpyDeviceToHost));
-          KR_HIP(hipMemcpy(hb.data(), b[k], hb.size() * sizeof(float), hipMemcpyDeviceToHost));
-        } else {
-          std::memcpy(hw.data(), W[k], hw.size() * sizeof(float));
-          std::memcpy(hb.data(), b[k], hb.size() * sizeof(float));
-        }
-        std::vector<float> w32((size_t)groups[k] * 64 * 4, 0.f), b32(64, 0.f);
+        std::vector<uint32_t> w32((size_t)groups[k] * 64 * 4, PACK_ZERO), b32(64, PACK_ZERO);
         for (int lane = 0; lane < 64; ++lane) {
           const int row = k == 2 ? (lane & 31) : lane;
           const int k0 = k == 2 ? 32 * (lane >> 5) : 0;
@@ -741,25 +731,113 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
             for (int g = 0; g < groups[k]; ++g)
               for (int e = 0; e < 4; ++e) {
                 const int ui = k0 + 4 * g + e;
-                if (ui < in) w32[((size_t)g * 64 + lane) * 4 + e] = hw[(size_t)row * in + ui];
+                if (ui < in) w32[((size_t)g * 64 + lane) * 4 + e] = wc(k, (size_t)row * in + ui);
               }
-          if (lane < out && (k < 2 || lane < 32)) b32[lane] = hb[lane];
+          if (lane < out && (k < 2 || lane < 32)) b32[lane] = bc(k, lane);
         }
-        void *pw, *pb;
-        KR_HIP(hipMalloc(&pw, w32.size() * sizeof(float))); h->mlp_allocs.push_back(pw);
-        KR_HIP(hipMalloc(&pb, b32.size() * sizeof(float))); h->mlp_allocs.push_back(pb);
-        KR_HIP(hipMemcpy(pw, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
-        KR_HIP(hipMemcpy(pb, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
-        mf.w32[k] = md.w32[k] = static_cast<float*>(pw);
-        mf.b32[k] = md.b32[k] = static_cast<float*>(pb);
+        add(std::move(w32), PACK_F32, (const void**)&mf.w32[k], (const void**)&md.w32[k]);
+        add(std::move(b32), PACK_F32, (const void**)&mf.b32[k], (const void**)&md.b32[k]);
       }
       mf.f32_ok = md.f32_ok = 1;
     }
-    mf.mfma_ok = md.mfma_ok = h->mfma_mlp ? 1 : 0;
+    mf.mfma_ok = md.mfma_ok = 1;  // (kr_set_mlp applies the option "mfma_mlp" on every call)
     mf.jvp_ok = md.jvp_ok = (n_layers == 2 || dims[2] <= 64 * 3) ? 1 : 0;  // MJ_ACT_SLOTS - 1 chunks of the second hidden layer
   }
-  h->mlp_f = mf;
-  h->mlp_d = md;
+  if ((int)jobs.size() > PACK_MAX_JOBS) { set_error("kr_set_mlp: too many packed buffers"); return KR_E_ARG; }
+  // one arena for every buffer (256-byte aligned pieces), one index table
+  const size_t esz[3] = {4, 8, 2};
+  size_t arena_bytes = 0, total = 0;
+  std::vector<size_t> off(jobs.size());
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    off[j] = arena_bytes;
+    arena_bytes += (jobs[j].code.size() * esz[jobs[j].type] + 255) / 256 * 256;
+    total += jobs[j].code.size();
+  }
+  if (total >= 0xFFFFFFF0ull) { set_error("kr_set_mlp: network too large"); return KR_E_ARG; }
+  KR_HIP(hipMalloc(&P.arena, arena_bytes));
+  KR_HIP(hipMalloc(&P.idx, total * sizeof(uint32_t)));
+  KR_HIP(hipMalloc(&P.staging, P.src_off[2 * n_layers] * sizeof(float)));
+  std::vector<uint32_t> all(total);
+  P.jobs.n = (int)jobs.size();
+  size_t pos = 0;
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    P.jobs.start[j] = (uint32_t)pos;
+    P.jobs.dst[j] = P.arena + off[j];
+    P.jobs.type[j] = (uint8_t)jobs[j].type;
+    *jobs[j].t0 = P.arena + off[j];
+    if (jobs[j].t1) *jobs[j].t1 = P.arena + off[j];
+    std::memcpy(all.data() + pos, jobs[j].code.data(), jobs[j].code.size() * sizeof(uint32_t));
+    pos += jobs[j].code.size();
+  }
+  P.jobs.start[jobs.size()] = (uint32_t)pos;
+  KR_HIP(hipMemcpy(P.idx, all.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return KR_OK;
+}
+}  // namespace kr
+
+extern "C" {
+
+int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* acts, const float* const* W,
+               const float* const* b, int src_on_device, void* stream) {
+  KR_CHECK_H(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc_order_ = order_stream(h, s)) return rc_order_;
+  h->mlp_f = MlpDev<float>{};
+  h->mlp_d = MlpDev<double>{};
+  if (n_layers == 0) return KR_OK;  // (the plan of the last shape stays cached)
+  if (n_layers < 0 || n_layers > KR_MAX_LAYERS) {
+    set_error("n_layers out of range");
+    return KR_E_ARG;
+  }
+  KR_CHECK_PTR(dims); KR_CHECK_PTR(acts); KR_CHECK_PTR(W); KR_CHECK_PTR(b);
+  const int want_in = h->params.nn_input_history ? 53 : 28;
+  if (dims[0] != want_in || dims[n_layers] != 25) {
+    set_error("MLP must map " + std::to_string(want_in) + " -> 25 (cosserat_ode_torch.py:60-62)");
+    return KR_E_ARG;
+  }
+  uint64_t key = 1469598103934665603ull;  // FNV-1a over the shape
+  auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+  mix((uint64_t)n_layers);
+  for (int k = 0; k <= n_layers; ++k) {
+    if (dims[k] <= 0) { set_error("bad layer width"); return KR_E_ARG; }
+    mix((uint64_t)dims[k]);
+  }
+  for (int k = 0; k < n_layers; ++k) {
+    if (acts[k] < KR_ACT_NONE || acts[k] > KR_ACT_ELU) { set_error("bad activation code"); return KR_E_ARG; }
+    KR_CHECK_PTR(W[k]); KR_CHECK_PTR(b[k]);
+    mix((uint64_t)acts[k] + 0x100);
+  }
+  if (!h->mlp_plan || h->mlp_plan->key != key) {
+    // another shape: the old buffers may still be read by launches in flight
+    KR_HIP(hipDeviceSynchronize());
+    free_mlp_plan(h);
+    h->mlp_plan = new kr_mlp_plan;
+    if (int rc = build_mlp_plan(h, n_layers, dims, acts, *h->mlp_plan)) {
+      free_mlp_plan(h);
+      return rc;
+    }
+    h->mlp_plan->key = key;
+  }
+  kr_mlp_plan& P = *h->mlp_plan;
+  for (int k = 0; k < n_layers; ++k) {
+    if (src_on_device) {
+      P.jobs.src[2 * k] = W[k];
+      P.jobs.src[2 * k + 1] = b[k];
+    } else {
+      KR_HIP(hipMemcpyAsync(P.staging + P.src_off[2 * k], W[k], sizeof(float) * dims[k] * dims[k + 1], hipMemcpyHostToDevice, s));
+      KR_HIP(hipMemcpyAsync(P.staging + P.src_off[2 * k + 1], b[k], sizeof(float) * dims[k + 1], hipMemcpyHostToDevice, s));
+      P.jobs.src[2 * k] = P.staging + P.src_off[2 * k];
+      P.jobs.src[2 * k + 1] = P.staging + P.src_off[2 * k + 1];
+    }
+  }
+  const uint32_t total = P.jobs.start[P.jobs.n];
+  int grid = (int)((total + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(kr::mlp_pack_kernel, dim3(grid), dim3(256), 0, s, P.jobs, P.idx);
+  KR_HIP(hipGetLastError());
+  h->mlp_f = P.mf;
+  h->mlp_d = P.md;
+  h->mlp_f.mfma_ok = h->mlp_d.mfma_ok = (P.mf.mfma_ok && h->mfma_mlp) ? 1 : 0;
   return KR_OK;
 }
 

@@ -66,7 +66,7 @@ struct kr_handle {
   // MLP
   kr::MlpDev<float> mlp_f{};
   kr::MlpDev<double> mlp_d{};
-  std::vector<void*> mlp_allocs;
+  struct kr_mlp_plan* mlp_plan = nullptr;  // packed buffers + gather plan of the current network shape (kr_api.hip)
   // lazily grown scratch (history fallback, MLP activation spill)
   void* ws = nullptr;
   void* pred_buf = nullptr;   // predictor images of the one-launch-per-step multiple-shooting path

@@ -1650,7 +1650,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void ms_sim_kernel(const RodCon
   S.quick_ok = A.residual_test != 0;
   S.lowp_allowed = NN && sizeof(T) == 8 && A.nn_lowp != 0 && M.f32_ok != 0;
   S.bo_allowed = NN && A.nn_base_only != 0 && (sizeof(T) == 8 ? M.n_layers == 3 && M.otiles[1] == 4 : M.f32_ok != 0);
-  S.lowp_first = true;  // (from the straight rod / a fresh call the first steps take three sweeps and more)
+  // from the straight rod / a fresh call the first steps take three sweeps and more; a call that resumes a steady trajectory
+  // through the predictor image starts like the steps it continues (full-precision first sweep) until a step says otherwise
+  S.lowp_first = !(img && A.pred_load && !resumed);
   T Gguess = lane < 6 ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   T tens[4];

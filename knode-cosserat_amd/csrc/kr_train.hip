@@ -482,7 +482,7 @@ int kr_mlp_forward(kr_handle* h, int64_t Q, int n_layers, const int32_t* dims, c
   if (int rc_order_ = order_stream(h, s)) return rc_order_;
   if (h->fused_mlp && fused_mlp_supported(n_layers, dims, acts, in_pad)) {
     KR_CHECK_PTR(ws);
-    if (ws == h->frag_ws && W[0] != h->frag_params) h->frag_ws = nullptr;  // (another network's fragments go into this workspace)
+    if (ws == h->frag_ws) h->frag_ws = nullptr;  // (this call packs its own fragments into the workspace: whatever layout kr_train_epoch left there is gone)
     return fused_mlp_forward(Q, n_layers, dims, acts, W, b, x, out, ws, s);
   }
   MlpWs w = carve_ws(ws, n_layers, dims, Q);
@@ -667,7 +667,7 @@ int kr_mlp_forward_loss(kr_handle* h, int64_t S, int K, int n_layers, const int3
       KR_HIP(hipMalloc(&h->loss_scratch, 4096 * sizeof(float)));  // one partial per workgroup of the forward kernel
     }
     FusedLoss fl{base, target_rows, dout, loss, h->loss_scratch, (float)h->derived.ds, (float)(1.0 / denom), K};
-    if (ws == h->frag_ws && W[0] != h->frag_params) h->frag_ws = nullptr;  // (another network's fragments go into this workspace)
+    if (ws == h->frag_ws) h->frag_ws = nullptr;  // (this call packs its own fragments into the workspace: whatever layout kr_train_epoch left there is gone)
     return fused_mlp_forward(Q, n_layers, dims, acts, W, b, x, out, ws, s, &fl);
   }
   KR_CHECK_PTR(out);

@@ -121,7 +121,9 @@ class KnodeTrainer:
         self.keep_pred = keep_pred
         self.group = group
         self.fused_epoch = True   # kr_train_epoch (one call per epoch) where the network is one the fused kernels serve
-        self._repack = False
+        # the first epoch always packs: the handle judges its fragment copies by pointer identity, and torch's caching
+        # allocator hands a new trainer the addresses of a freed one
+        self._repack = True
         self._param_versions = None
         self.time_allreduce = False
         self.allreduce_events = []

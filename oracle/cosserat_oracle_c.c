@@ -221,3 +221,42 @@ int orc_simulate(const orc_params* P, int T, const double* ctl, double* tip_out,
   free(y); free(z); free(yp); free(zp); free(yh); free(zh);
   return bad;
 }
+
+#ifdef ORC_SELFTEST
+/* `make asan`: the same file as a standalone program under -fsanitize=address,undefined (SURVEY section 5 asks for a
+ * sanitizer build of the CPU restatement).  setup_robot(None) parameters (knode.py:11-20), per-rod sine tensions, N = 10,
+ * 20, 100, 400 with and without the trajectory buffer; exit code 1 on a non-finite tip or an unconverged step. */
+#include <stdio.h>
+int main(void) {
+  const int Ns[4] = {10, 20, 100, 400}, Ts[4] = {40, 40, 20, 8};
+  const double pi = 3.14159265358979323846;
+  int fail = 0;
+  for (int c = 0; c < 4; ++c) {
+    orc_params P;
+    memset(&P, 0, sizeof(P));
+    P.L = 0.635; P.E = 2.757903e9; P.r = 0.003175; P.rho = 1411.6751; P.del_t = 0.05; P.N = Ns[c];
+    P.vstar[2] = 1.0; P.g[2] = -9.81; P.h0[0] = 1.0;
+    P.Bbt[0] = P.Bbt[4] = P.Bbt[8] = 3e-2;
+    P.C[0] = P.C[1] = P.C[2] = 1e-4;
+    for (int k = 0; k < 4; ++k) {
+      const double th = pi / 4 + k * pi / 2;
+      P.tendon_dirs[3 * k] = cos(th); P.tendon_dirs[3 * k + 1] = sin(th);
+    }
+    const int T = Ts[c];
+    double* ctl = (double*)malloc(sizeof(double) * 4 * T);
+    double* tip = (double*)malloc(sizeof(double) * 3 * T);
+    double* traj = (double*)malloc(sizeof(double) * 25 * (size_t)Ns[c] * (T + 1));
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < 4; ++k) ctl[4 * t + k] = 6.0 + sin(2 * pi * (t + 1) * P.del_t / 1.3 + 0.4 + k * pi / 2);
+    for (int with_traj = 0; with_traj < 2; ++with_traj) {
+      const int bad = orc_simulate(&P, T, ctl, tip, with_traj ? traj : NULL);
+      int finite = 1;
+      for (int i = 0; i < 3 * T; ++i) finite &= isfinite(tip[i]) != 0;
+      printf("N=%d T=%d traj=%d unconverged=%d tip=(%.6f %.6f %.6f)\n", Ns[c], T, with_traj, bad, tip[3 * T - 3], tip[3 * T - 2], tip[3 * T - 1]);
+      if (bad != 0 || !finite) fail = 1;
+    }
+    free(ctl); free(tip); free(traj);
+  }
+  return fail;
+}
+#endif

@@ -384,3 +384,21 @@ def test_bc_simulate_with_mlp(name):
     D = bc_params(g, int(g[f"nn_{name}_N"])).derived()
     traj = orc.simulate(D, g[f"nn_{name}_ctl"], mlp=mlp)
     assert rel_l2(traj[:, :25], g[f"nn_{name}_traj"]) < 1e-9
+
+
+def test_c_oracle_under_sanitizers():
+    """`make -C oracle asan`: the C restatement as a standalone program under AddressSanitizer + UBSan,
+    N = 10 / 20 / 100 / 400 with and without the trajectory buffer.  CPU build only (GPU sanitizers are not available on
+    this pool)."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.run(["make", "-C", here, "asan"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(here, "lib", "oracle_c_asan")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+    assert r.stdout.count("unconverged=0") == 8, r.stdout
