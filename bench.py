@@ -55,7 +55,8 @@ def rank_controls(B, world, rank, steps, del_t, first_step=1):
 
 def committed_profile(B, N, dtype, path, kind):
     """Per-rod-step figures from the newest committed rocprofv3 --pmc summary of this workload
-    (profiles/*pmc_<kind>.json, written by tools/summarise_profiles.py); None if there is none."""
+    (profiles/*pmc_<kind>.json, written by tools/profile_summary.py, which attributes a counter row to the workload only
+    if kernel instantiation AND dispatch duration match the profiled process's own timing); None if there is none."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{kind}.json"))):
@@ -70,6 +71,42 @@ def committed_profile(B, N, dtype, path, kind):
         d["_file"] = os.path.basename(f)
         best = d
     return best
+
+
+MFMA_PEAK_TF = {"mfma_f64": 78.6, "mfma_f32": 157.3, "mfma_bf16": 2516.6}
+
+
+def executed_roofline(leg, units_per_s, dtype):
+    """`roofline.executed` of a leg: the arithmetic the kernel actually executed per unit (counter pass of the committed
+    profile, profiles/*_pmc_ops.json: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, SQ_INSTS_VALU_MFMA_MOPS_* x 512) at
+    THIS run's rate, against the vector peak of the run's type and - for matrix work - against the dense MFMA peak of each
+    operand type (the time the matrix pipes would need at peak over the time the launch took)."""
+    import glob
+    entry, src = None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_ops.json"))):
+        try:
+            e = json.load(open(f)).get("legs", {}).get(leg)
+        except Exception:
+            continue
+        if e:
+            entry, src = e, os.path.basename(f)
+    if entry is None:
+        return None
+    fl = entry["executed_flops_per_unit"]
+    vkey = "valu_f64" if dtype == "f64" else "valu_f32"
+    vpeak = FP64_VALU_PEAK_TF if dtype == "f64" else 157.3
+    out = {"source": src, "flops_per_unit": fl, "valu_insts_per_unit": entry.get("valu_insts_per_unit"),
+           "how": "counter-measured operations per unit of the committed profile x this run's units per second; vector flops "
+                  "assume 64 active lanes per instruction (upper bound: the step kernels run 58 of 64)"}
+    if fl.get(vkey):
+        tf = fl[vkey] * units_per_s / 1e12
+        out["valu"] = {"achieved": round(tf, 3), "peak": vpeak, "unit": "TFLOP/s", "frac": round(tf / vpeak, 5)}
+    m = {k: fl[k] * units_per_s / 1e12 for k in MFMA_PEAK_TF if fl.get(k)}
+    if m:
+        out["mfma"] = {"achieved": {k: round(v, 3) for k, v in m.items()}, "peaks": {k: MFMA_PEAK_TF[k] for k in m}, "unit": "TFLOP/s",
+                       "frac": round(sum(v / MFMA_PEAK_TF[k] for k, v in m.items()), 5)}
+    out["frac"] = round((out.get("valu", {}).get("frac", 0.0)) + (out.get("mfma", {}).get("frac", 0.0)), 5)
+    return out
 
 
 def cpu_model():
@@ -185,32 +222,49 @@ EXTRA_REFS = {  # name: (seed, N, steps, B, mlp sizes)
 }
 
 
-def run_extras(torch, dev_index, refs, log):
-    """The other BASELINE.json configurations on this GPU, one sub-object each."""
+def extra_legs(refs=None):
+    """The other BASELINE.json configurations as a table: name -> (function of bench_legs, positional arguments
+    after (torch, dev_index), keyword arguments).  bench.py runs every entry under `extra`; tools/leg_only.py runs ONE of
+    them under rocprofv3 with the same arguments, so a profile and the driver line describe the same launches."""
     import bench_legs as bl
     refs = refs or {}
     mlp = bl.mlp_weights(NN_SIZES, 7)
-    legs = {}
+    return {
+        "cfg2": ("forward_leg", (256, 100, 200, 60, "f64", 1234), {"ref_tips": refs.get("cfg2")}),
+        "cfg3_nn_f64": ("forward_leg", (1024, 100, 64, 0, "f64", SEED), {"mlp": mlp, "ref_tips": refs.get("cfg3_nn"), "repeats": 2}),
+        "cfg3_nn_f32": ("forward_leg", (1024, 100, 64, 0, "f32", SEED), {"mlp": mlp, "ref_tips": refs.get("cfg3_nn"), "repeats": 2}),
+        "cfg3_train_epoch": ("train_leg", (1024, 64, 100, [22, 67, 99], [64, 64]), {}),
+        "cfg3_mlp_literal": ("mlp_literal_leg", (193536,), {}),
+        "cfg4_shard_epoch": ("train_leg", (512, 30, 10, [3, 5, 7, 9], [512]), {}),
+        "cfg5": ("forward_leg", (512, 400, 60, 30, "f64", 1237), {"ref_tips": refs.get("cfg5")}),
+        "cfg5_f32": ("forward_leg", (512, 400, 60, 30, "f32", 1237), {"ref_tips": refs.get("cfg5")}),
+        "cfg5_tolerance_sweep": ("tolerance_sweep_leg", (), {}),
+        "headline_full_trajectory": ("forward_leg", (1024, 100, 200, 60, "f64", SEED),
+                                     {"full_trajectory": True, "ref_tips": refs.get("headline_full_trajectory")}),
+    }
 
-    def leg(name, fn, *a, **k):
+
+def run_extras(torch, dev_index, refs, log):
+    """Runs every leg of extra_legs() on this GPU, one sub-object each."""
+    import bench_legs as bl
+    legs = {}
+    for name, (fn, a, k) in extra_legs(refs).items():
         t0 = time.perf_counter()
         try:
-            legs[name] = fn(*a, **k)
+            legs[name] = getattr(bl, fn)(torch, dev_index, *a, **k)
         except Exception as e:  # a leg that fails must not take the headline line with it
             legs[name] = {"error": f"{type(e).__name__}: {e}"}
         legs[name]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+        r = legs[name].get("roofline")
+        if r is not None and fn == "forward_leg" and legs[name].get("kernel_ms_per_step"):
+            key = "headline" if name == "headline_full_trajectory" else name
+            ex = executed_roofline(key, legs[name]["B"] / (legs[name]["kernel_ms_per_step"] * 1e-3), legs[name]["dtype"])
+            r["executed"] = ex
+            if r.get("frac") is None and ex is not None:
+                # MLP-on legs: the nominal count is not a utilisation (bench_legs.forward_leg); the executed one is
+                r["frac"] = ex["frac"]
+                r["frac_is"] = "executed (roofline.executed): matrix-pipe time at dense peak per operand type + vector flops at the vector peak, over the launch time"
         log(f"extra {name}: {legs[name].get('value')} {legs[name].get('unit')} ({legs[name]['leg_wall_s']} s)")
-
-    leg("cfg2", bl.forward_leg, torch, dev_index, 256, 100, 200, 60, "f64", 1234, ref_tips=refs.get("cfg2"))
-    leg("cfg3_nn_f64", bl.forward_leg, torch, dev_index, 1024, 100, 64, 0, "f64", SEED, mlp=mlp,
-        ref_tips=refs.get("cfg3_nn"), repeats=2)
-    leg("cfg3_nn_f32", bl.forward_leg, torch, dev_index, 1024, 100, 64, 0, "f32", SEED, mlp=mlp,
-        ref_tips=refs.get("cfg3_nn"), repeats=2)
-    leg("cfg3_train_epoch", bl.train_leg, torch, dev_index, 1024, 64, 100, [22, 67, 99], [64, 64])
-    leg("cfg4_shard_epoch", bl.train_leg, torch, dev_index, 512, 30, 10, [3, 5, 7, 9], [512])
-    leg("cfg5", bl.forward_leg, torch, dev_index, 512, 400, 60, 30, "f64", 1237, ref_tips=refs.get("cfg5"))
-    leg("headline_full_trajectory", bl.forward_leg, torch, dev_index, 1024, 100, 200, 60, "f64", SEED,
-        full_trajectory=True, ref_tips=refs.get("headline_full_trajectory"))
     return legs
 
 
@@ -498,6 +552,7 @@ def main():
                 "algorithmic_flops_per_rod_step": flops_per_rod_step,
                 "achieved_is": "nominal: SURVEY 8d formula flops (k = 3 FD-Newton iterations), not executed flops",
                 "executed_valu_insts_per_rod_step": instr_per_unit and round(instr_per_unit, 1),
+                "executed": executed_roofline("headline", units_per_launch / (kernel_ms * 1e-3), args.dtype),
                 "valu_issue_frac": valu_issue,
                 "hbm": {"achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(hbm_achieved / HBM_PEAK_GBS, 7), "algorithmic_bytes_per_launch": alg_bytes,

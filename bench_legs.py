@@ -271,6 +271,103 @@ def train_leg(torch, dev_index, M, T, N, key_pts, layers, ctl_seed=1236, epochs=
     }
 
 
+def mlp_literal_leg(torch, dev_index, Q, repeats=7):
+    """BASELINE.json configs[2] read literally: a KNODE residual MLP 18 -> 64 -> 64 -> 6 (ELU), forward + backward over
+    Q rows as a bare GEMM micro-benchmark (SURVEY 8d cfg3 asks to report it beside the 28 -> 64 -> 64 -> 25 network of the
+    reference's I/O contract, which `cfg3_train_epoch` times).  There is no loss for 6 outputs in the reference: dout is a
+    fixed random matrix.  kr_mlp_forward + kr_mlp_backward through the C ABI, median of `repeats` pairs (HIP events)."""
+    import ctypes as C
+    import krod_native as kn
+    dev = f"cuda:{dev_index}"
+    h = make_robot(100, dev_index)._native()
+    dims = [18, 64, 64, 6]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    Ws = [torch.randn(dims[k + 1], dims[k], device=dev, generator=gen) * 0.1 for k in range(3)]
+    bs = [torch.randn(dims[k + 1], device=dev, generator=gen) * 0.1 for k in range(3)]
+    dWs = [torch.zeros_like(w) for w in Ws]
+    dbs = [torch.zeros_like(b) for b in bs]
+    x = torch.zeros((Q, 32), device=dev)
+    x[:, :18] = torch.randn(Q, 18, device=dev, generator=gen)
+    out = torch.zeros((Q, 32), device=dev)
+    dout = torch.zeros((Q, 32), device=dev)
+    dout[:, :6] = torch.randn(Q, 6, device=dev, generator=gen)
+    dims_c = (C.c_int32 * 4)(*dims)
+    acts_c = (C.c_int32 * 3)(kn.ACT_ELU, kn.ACT_ELU, kn.ACT_NONE)
+    ws = torch.empty(max(h.lib.kr_mlp_ws_bytes(3, dims_c, Q), 16), dtype=torch.uint8, device=dev)
+    Wp = (C.c_void_p * 3)(*[w.data_ptr() for w in Ws])
+    bp = (C.c_void_p * 3)(*[b.data_ptr() for b in bs])
+    dWp = (C.c_void_p * 3)(*[w.data_ptr() for w in dWs])
+    dbp = (C.c_void_p * 3)(*[b.data_ptr() for b in dbs])
+
+    def fb():
+        kn.check(h.lib.kr_mlp_forward(h._h, Q, 3, dims_c, acts_c, Wp, bp, kn._ptr(x), 32, kn._ptr(out), kn._ptr(ws), kn._stream()))
+        kn.check(h.lib.kr_mlp_backward(h._h, Q, 3, dims_c, acts_c, Wp, kn._ptr(x), 32, kn._ptr(dout), kn._ptr(ws), dWp, dbp,
+                                       kn._stream()))
+    for _ in range(3):
+        fb()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(repeats)]
+    for a, b in evs:
+        a.record()
+        fb()
+        b.record()
+    torch.cuda.synchronize()
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    med = statistics.median(us)
+    # parity of this very call against fp64 torch on a slice (the micro-benchmark must not time a wrong answer)
+    n_chk = 4096
+    import torch.nn.functional as F
+    a = x[:n_chk, :18].double()
+    for k in range(3):
+        a = a @ Ws[k].double().t() + bs[k].double()
+        if k < 2:
+            a = F.elu(a)
+    err = float((out[:n_chk, :6].double() - a).norm() / a.norm())
+    mac = sum(p * q for p, q in zip(dims[:-1], dims[1:]))
+    tf = 6 * Q * mac / (med * 1e-6) / 1e12
+    return {"value": round(Q / (med * 1e-6), 1), "unit": "rows/s", "us_per_fwd_bwd": round(med, 2), "us_min": round(us[0], 2),
+            "us_max": round(us[-1], 2), "rows": Q, "network": "18->64->64->6 (BASELINE-literal), ELU", "dtype": "f32",
+            "kernel": "kr_mlp_forward + kr_mlp_backward (kr::mlp_fwd_fused_kernel / mlp_fwd3_kernel, kr::mlp_bwd3* , slab reduction)",
+            "forward_rel_l2_vs_fp64_torch": err,
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(tf / FP32_PEAK_TF, 5),
+                         "how": "6 x rows x sum(in x out) useful fp32 flops (forward + both backward products) over the median "
+                                "forward + backward time, against the fp32 MFMA peak"}}
+
+
+def tolerance_sweep_leg(torch, dev_index):
+    """BASELINE cfg5 "fp64 vs fp32 tolerance sweep": the reference's own N = 400 run (tests/golden/sim_n400.npz, produced by
+    the unmodified reference) re-simulated at four Newton tolerances per arithmetic type; tip rel L2 against the reference."""
+    dev = f"cuda:{dev_index}"
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "sim_n400.npz"))
+    r = make_robot(400, dev_index)
+    h = r._native()
+    out = {"fixture": "tests/golden/sim_n400.npz (reference run: one rod, N = 400, sine tensions)", "unit": "tip rel L2 vs reference",
+           "steps": int(g["ctl"].shape[0])}
+    t0 = time.perf_counter()
+    for dname, dt, tols in (("f64", torch.float64, (1e-6, 1e-8, 1e-10, 1e-12)), ("f32", torch.float32, (1e-3, 1e-4, 1e-5, 1e-6))):
+        row = {}
+        for tol in tols:
+            c = torch.as_tensor(g["ctl"][None], device=dev).to(dt).contiguous()
+            T = c.shape[1]
+            st = h.new_state(1, dt, n_slots=T + 1)
+            h.init_straight(st[0])
+            G = torch.zeros((1, 6), dtype=dt, device=dev)
+            tip = torch.empty((1, T, 3), dtype=dt, device=dev)
+            status = torch.zeros((1, T), dtype=torch.int32, device=dev)
+            h.simulate(c, st, G, tip=tip, status=status, tol=tol)
+            torch.cuda.synchronize()
+            # the reference drops its last solve and lists the initial tip first (knode.py:96-102)
+            got = np.concatenate([st[0][0, -1, 12:15].cpu().numpy()[None], tip[0].cpu().numpy()])[:T].astype(np.float64)
+            row[f"{tol:.0e}"] = {"tip_rel_l2": _rel(got, g["tip"]), "unconverged": int((status != 0).sum())}
+        out[dname] = row
+    out["value"] = out["f64"]["1e-08"]["tip_rel_l2"]
+    out["seconds"] = round(time.perf_counter() - t0, 3)
+    out["contract"] = "tip rel L2 <= 1e-5 (BASELINE north_star): met by every fp64 tolerance and by fp32 at tol <= 1e-5"
+    return out
+
+
 def train_dp_leg(torch, dist, dev_index, world, rank, backend, M_total=4096, T=30, N=10, key_pts=(3, 5, 7, 9),
                  layers=(512,), epochs=50, check=True):
     """BASELINE cfg4: the training loop of physics_train.py:306-408 on M_total trajectories sharded over the ranks
@@ -314,6 +411,17 @@ def train_dp_leg(torch, dist, dev_index, world, rank, backend, M_total=4096, T=3
     else:
         ranks_seen = 1
     ar_us = sorted(a.elapsed_time(b) * 1e3 for a, b in tr.allreduce_events)
+    # the same shard WITHOUT the collective (group=False): what the all-reduce and its stream hand-off add to an epoch
+    rob3, _ = torch_rod(torch, dev, N, list(layers))
+    local = KnodeTrainer(rob3, traj, torch.as_tensor(ctl[lo:hi], device=dev).float().contiguous(), list(key_pts), group=False)
+    for _ in range(2):
+        local.step(sync_loss=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        local.step(sync_loss=False)
+    torch.cuda.synchronize()
+    local_us = (time.perf_counter() - t0) / epochs * 1e6
     losses = tr.losses()
     n_floats = int(tr.bucket.flat.numel())
     out = None
@@ -325,6 +433,13 @@ def train_dp_leg(torch, dist, dev_index, world, rank, backend, M_total=4096, T=3
             "backend": backend + (" (RCCL)" if backend == "nccl" else " (rehearsal: CPU tensors)"),
             "allreduce_us": round(statistics.median(ar_us), 2) if ar_us else None,
             "allreduce_us_min_max": [round(ar_us[0], 2), round(ar_us[-1], 2)] if ar_us else None,
+            "allreduce_us_stats": {"min": round(ar_us[0], 2), "median": round(statistics.median(ar_us), 2),
+                                   "max": round(ar_us[-1], 2), "n": len(ar_us),
+                                   "what": "HIP events around dist.all_reduce on the compute stream, rank 0"} if ar_us else None,
+            "epoch_us_with_allreduce": round(wall / epochs * 1e6, 2),
+            "epoch_us_without_allreduce": round(local_us, 2),
+            "epoch_us_what": "wall per epoch of rank 0's shard: phase 1 + all-reduce + phase 2 (MAX over ranks) against the "
+                             "same shard through the single-call epoch with no collective (rank 0)",
             "floats": n_floats, "loss_first": losses[0], "loss_last": losses[-1], "ranks_seen": ranks_seen,
             "data_unconverged": bad,
             "what": "per epoch: forward + loss + backward on the rank's shard, one all-reduce(SUM) of the flat fp32 "

@@ -506,3 +506,28 @@ def test_cfg3_full_size_training_step(torch_cuda):
     for k, (p, q_) in enumerate(zip(rob.nn_models.parameters(), opt.param_groups[0]["params"])):
         want_p = q_.detach().clamp(min=0) if k % 2 == 0 else q_.detach()
         assert float((p.detach() - want_p).abs().max()) < 1e-6
+    # (4) the SAME epoch through kr_train_epoch (tr.step(): mlp_fwd3_kernel + loss epilogue, mlp_bwd3_kernel,
+    # train_tail_kernel - the kernels bench.py's cfg3_train_epoch leg times) from the same initial weights, against the
+    # fp64 torch loss / gradients and torch.optim.Adam above, not against its separate-call sibling
+    rob2 = CosseratRodTorch(DEV, 64)
+    setup_robot(rob2, "damping")
+    rob2.N = N
+    rob2.compute_intermediate_terms()
+    mods2 = [nn.Linear(28, 64), nn.ELU(), nn.Linear(64, 64), nn.ELU(), nn.Linear(64, 25)]
+    rob2.nn_models = nn.ModuleList(mods2).to(DEV)
+    with torch.no_grad():
+        for a, b in zip(rob2.nn_models.parameters(), before):
+            a.copy_(b)
+    tr2 = KnodeTrainer(rob2, traj, controls, kp)
+    l_epoch = tr2.step()
+    assert tr2.fused_epoch
+    assert abs(l_epoch - float(total)) < 1e-4 * abs(float(total))
+    off = 0
+    for k, (p, q_, gref) in enumerate(zip(rob2.nn_models.parameters(), opt.param_groups[0]["params"], ref_net.parameters())):
+        want_p = q_.detach().clamp(min=0) if k % 2 == 0 else q_.detach()
+        assert float((p.detach() - want_p).abs().max()) < 1e-6, k
+        n = p.numel()
+        g64 = gref.grad.reshape(-1)
+        m = tr2.exp_avg[off:off + n].double()
+        assert float((m - 0.1 * g64).norm() / (0.1 * g64).norm()) < 2e-4, k  # exp_avg after step 1 = (1 - beta1) g
+        off += n

@@ -170,6 +170,28 @@ def test_cfg4_shard_training_step(torch_cuda, N):
         # as test_cfg3_full_size_training_step)
         assert float((a.detach() - b.detach()).abs().max()) < 1e-6
     assert float(rob.nn_models[0].weight.min()) >= 0 and float(rob.nn_models[2].weight.min()) >= 0
+    # the SAME epoch through kr_train_epoch (tr.step(): mlp_fwd2_kernel + loss epilogue, mlp_bwd2_kernel, train_tail_kernel -
+    # what bench.py's cfg4_shard_epoch and train_dp legs time) from the same initial weights, against fp64 torch +
+    # torch.optim.Adam above
+    rob2 = CosseratRodTorch(DEV, 512)
+    setup_robot(rob2, "damping")
+    rob2.N = N
+    rob2.compute_intermediate_terms()
+    with torch.no_grad():
+        for a, b in zip(rob2.nn_models.parameters(), w0):
+            a.copy_(b)
+    tr2 = KnodeTrainer(rob2, traj, controls, kp)
+    l_epoch = tr2.step()
+    assert tr2.fused_epoch
+    assert abs(l_epoch - float(total)) < 1e-4 * abs(float(total))
+    off = 0
+    for k, (a, b, gref) in enumerate(zip(rob2.nn_models.parameters(), params32, ref_net.parameters())):
+        assert float((a.detach() - b.detach()).abs().max()) < 1e-6, k
+        n = a.numel()
+        g64 = gref.grad.reshape(-1)
+        m = tr2.exp_avg[off:off + n].double()
+        assert float((m - 0.1 * g64).norm() / (0.1 * g64).norm()) < 2e-4, k  # exp_avg after step 1 = (1 - beta1) g
+        off += n
     # a second epoch runs on the updated weights and lowers or keeps the loss scale finite
     l2 = float(tr.step())
     assert np.isfinite(l2)

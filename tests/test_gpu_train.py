@@ -147,6 +147,61 @@ def test_fused_trainer(torch_cuda, path, kp, keep_pred):
     assert l1 < l0
 
 
+@pytest.mark.parametrize("path,kp", [("fast", [3, 5, 7, 9]), ("slow", [2, 6, 9])])
+def test_train_epoch_call_vs_reference_epoch(torch_cuda, path, kp):
+    """kr_train_epoch itself (ONE tr.step() = mlp_fwd2_kernel + loss epilogue, mlp_bwd2_kernel, train_tail_kernel) from the
+    golden weights against the reference's own epoch (physics_train.py:306-408 / :209-304, captured in train_step.npz): the
+    loss it logs, the post-Adam + clamp weights, and - through the update, which is lr * sign-like at step 1 - the
+    gradients: Adam's first step moves a parameter by lr * g / (|g| + eps), so the moments are checked against the
+    reference gradients directly (exp_avg = 0.1 g, exp_avg_sq = 0.001 g^2)."""
+    torch = torch_cuda
+    from krod_train import KnodeTrainer
+    g = load_golden("train_step")
+    rob = make_robot(torch, g)
+    traj = torch.tensor(g["traj"], device=DEV)[None]
+    controls = torch.tensor(g["controls"], device=DEV)[None]
+    tr = KnodeTrainer(rob, traj, controls, kp)
+    loss = tr.step()
+    assert tr.fused_epoch, "the 28 -> 64 -> 25 network must be served by kr_train_epoch"
+    assert abs(loss - float(g[f"{path}_loss"])) < 2e-5 * abs(float(g[f"{path}_loss"]))
+    off = 0
+    for i, p in enumerate(rob.nn_models.parameters()):
+        n = p.numel()
+        ref_g = g[f"{path}_grad{i}"].reshape(-1)
+        m = tr.exp_avg[off:off + n].cpu().numpy()
+        v = tr.exp_avg_sq[off:off + n].cpu().numpy()
+        assert rel_l2(m, 0.1 * ref_g) < 2e-4, (i, rel_l2(m, 0.1 * ref_g))
+        assert rel_l2(v, 0.001 * ref_g ** 2) < 4e-4, (i, rel_l2(v, 0.001 * ref_g ** 2))
+        assert np.mean(np.abs(p.detach().cpu().numpy() - g[f"{path}_post{i}"]) < 2e-4) > 0.995
+        off += n
+    assert float(tr.bucket.flat.abs().max()) == 0.0  # the tail leaves the gradient buffer zeroed
+
+
+def test_second_trainer_on_the_same_robot_packs_afresh(torch_cuda):
+    """a trainer built on a robot whose previous trainer was freed gets the same workspace / parameter
+    addresses from torch's caching allocator; its first epoch must still run on ITS weights (the first epoch always packs)."""
+    torch = torch_cuda
+    from krod_train import KnodeTrainer
+    g = load_golden("train_step")
+    traj = torch.tensor(g["traj"], device=DEV)[None]
+    controls = torch.tensor(g["controls"], device=DEV)[None]
+    rob = make_robot(torch, g)
+    tr = KnodeTrainer(rob, traj, controls, [3, 5, 7, 9])
+    first = tr.step()
+    for _ in range(5):
+        tr.step()
+    ptrs = (tr.ws.data_ptr(), tr.flat_p.data_ptr())
+    del tr
+    with torch.no_grad():  # back to the golden weights: epoch 1 of the new trainer must reproduce `first`
+        rob.nn_models[0].weight.copy_(torch.tensor(g["mlp_W0"]))
+        rob.nn_models[0].bias.copy_(torch.tensor(g["mlp_b0"]))
+        rob.nn_models[2].weight.copy_(torch.tensor(g["mlp_W1"]))
+        rob.nn_models[2].bias.copy_(torch.tensor(g["mlp_b1"]))
+    tr2 = KnodeTrainer(rob, traj, controls, [3, 5, 7, 9])
+    again = tr2.step()
+    assert again == first, (again, first, (tr2.ws.data_ptr(), tr2.flat_p.data_ptr()) == ptrs)
+
+
 def test_native_adam_matches_torch(torch_cuda):
     """kr_adam_step against torch.optim.Adam + clamp over several epochs on the same data, incl. weight decay."""
     torch = torch_cuda

@@ -528,3 +528,76 @@ def test_integration_stub_runs():
     out = mod.simulate_gpu(robot, g["ctl"][:T])
     assert out.shape == (T + 1, 25, 20)
     assert rel_l2(out[:T, :3, -1], g["tip"][:T]) < 1e-8
+
+
+# ---- tools/profile_summary.py: a counter file of another workload must be refused -------------
+def _fake_profile_tree(tmp, tag, kernel_name, dur_ns, value_kb, own_ms_per_step=0.0285):
+    """gpurun_out-like tree: the bench line, and for the FETCH / WRITE passes the profiled process's own bench line plus a
+    counter_collection.csv with five dispatches of `kernel_name` lasting dur_ns each (and one unrelated torch kernel)."""
+    import json
+    G = os.path.join(tmp, "gpurun_out")
+    os.makedirs(G)
+    line = {"metric": "rod-steps/sec (N=100 segments, batch=1024)", "value": 35.9e6, "steps": 1000, "ms_per_step": 0.0285, "dtype": "f64",
+            "config": {"rods_per_gpu": 1024, "N": 100},
+            "roofline": {"kernel": "kr::mso_sim_kernel (persistent, overlapped steps)", "kernel_ms": 28.5, "launches": 1,
+                         "hbm": {"algorithmic_bytes_per_launch": 57344000}}}
+    open(os.path.join(G, f"{tag}_bench.json"), "w").write(json.dumps(line) + "\n")
+    own = dict(line, ms_per_step=own_ms_per_step)
+    hdr = ('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",'
+           '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value",'
+           '"Start_Timestamp","End_Timestamp"\n')
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        p = f"{tag}_bench_{'fetch' if cname == 'FETCH_SIZE' else 'write'}"
+        os.makedirs(os.path.join(G, p, "box"))
+        open(os.path.join(G, p + ".out"), "w").write("[bench] noise\n" + json.dumps(own) + "\n")
+        rows = [f'1,1,"Agent 2",1,7,7,65536,67,"void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float> >(int)",'
+                f'128,0,0,8,0,64,"{cname}",1024.0,1000,9000\n']
+        t = 100000
+        for d in range(2, 7):
+            rows.append(f'{d},{d},"Agent 2",1,7,7,262144,9,"{kernel_name}",256,0,0,128,0,96,"{cname}",{value_kb},{t},{t + dur_ns}\n')
+            t += dur_ns + 5000
+        open(os.path.join(G, p, "box", "7_counter_collection.csv"), "w").write(hdr + "".join(rows))
+    return G
+
+
+def _load_profile_summary():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("profile_summary", os.path.join(ROOT, "tools", "profile_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_profile_summary_accepts_the_right_kernel(tmp_path):
+    import json
+    ps = _load_profile_summary()
+    G = _fake_profile_tree(str(tmp_path), "t0", "void kr::mso_sim_kernel<double, true, 18, 1>(kr::RodConst<double>, kr::SimArgs<double>)",
+                           28_540_000, 5_306_000.0)
+    P = os.path.join(str(tmp_path), "profiles")
+    ps.summarise("t0", G, P, log=lambda m: None)
+    hbm = json.load(open(os.path.join(P, "t0_pmc_hbm.json")))
+    # write 5.306 GB + 2 x fetch 5.306 GB over 1.024 M rod-steps
+    assert abs(hbm["hbm_bytes_per_rod_step"] - 3 * 5_306_000.0 * 1024 / (1024 * 1000)) < 1.0
+    assert hbm["FETCH_SIZE_dispatches"] == 5 and "<double" in hbm["WRITE_SIZE_kernel_name"]
+
+
+@pytest.mark.parametrize("case", ["other_dtype", "other_duration", "other_run"])
+def test_profile_summary_refuses_a_mislabelled_counter_file(tmp_path, case):
+    """The round-4 accident restated: the raw directory holds `mso_sim_kernel<float, ...>` launches of 2.2 ms written by the
+    training script (or launches of the right type but the wrong length, or a process whose own timing disagrees with the
+    bench line) - nothing may be summarised under the headline's name."""
+    ps = _load_profile_summary()
+    name, dur, own = {
+        "other_dtype": ("void kr::mso_sim_kernel<float, true, 20, 1>(kr::RodConst<float>, kr::SimArgs<float>)", 2_200_000, 0.0285),
+        "other_duration": ("void kr::mso_sim_kernel<double, true, 18, 1>(kr::RodConst<double>, kr::SimArgs<double>)", 2_200_000, 0.0285),
+        "other_run": ("void kr::mso_sim_kernel<double, true, 18, 1>(kr::RodConst<double>, kr::SimArgs<double>)", 28_540_000, 0.0400),
+    }[case]
+    G = _fake_profile_tree(str(tmp_path), "t1", name, dur, 726_452.0, own_ms_per_step=own)
+    P = os.path.join(str(tmp_path), "profiles")
+    problems = ps.summarise("t1", G, P, log=lambda m: None)
+    assert problems and any("bench_fetch" in p for p in problems), problems
+    assert not os.path.exists(os.path.join(P, "t1_pmc_hbm.json"))
+    rows = ps.read_rows(os.path.join(G, "t1_bench_fetch", "box", "7_counter_collection.csv"))
+    if case != "other_run":
+        with pytest.raises(ps.ProfileMismatch):
+            ps.timed_dispatches(rows, "mso_sim_kernel", "f64", 28_500.0, "unit")
