@@ -325,6 +325,9 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, int64_t 
 // raw register image of a chunk, [block][unit tile][sample tile][lane] x 16 bytes: coalesced both ways, and exactly
 // the layout the consumer needs as B operand / for its T tile
 __device__ __forceinline__ void chunk_dump(float* __restrict__ base, int64_t rb, const FChunk& h, int lane) {
+#ifdef KR_ABL_NODUMP  // (timing ablation of a diagnostic build: the backward pass then reads stale images)
+  return;
+#endif
   f4* dst = reinterpret_cast<f4*>(base) + (size_t)rb * (4 * FT * 64) + lane;
 #pragma unroll
   for (int o = 0; o < 4; ++o)
@@ -578,14 +581,14 @@ __device__ __forceinline__ void fwd_rows(const FusedArgs& A, float* tx, float* t
       static_assert(FR == 32, "lane <-> row map of the loss epilogue");
       const int rl = lane & (FR - 1);
       const bool valid = rb * FR + rl < A.Q;
-      float e[3] = {0.f, 0.f, 0.f};
+      float e[3] = {0.f, 0.f, 0.f}, nq[5];
       {
         float q[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           q[c] = lane < FR ? tbt[rl * 25 + 3 + c] + A.lds * xcur[rl * OP + 3 + c] : tbt[FR * 25 + rl * 25 + 3 + c];
         if (!valid) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; }
-        q2e(q, e);
+        q2e_n(q, e, nq);  // (the lower lanes keep the normalised quaternion for the Jacobian-transpose product below)
       }
       float eo[3];
 #pragma unroll
@@ -597,7 +600,7 @@ __device__ __forceinline__ void fwd_rows(const FusedArgs& A, float* tx, float* t
           p[r] = tbt[lane * 25 + r] + (r < 19 ? A.lds : 1.f) * xcur[lane * OP + r];
           tgv[r] = tbt[FR * 25 + lane * 25 + r];
         }
-        loss_part += loss_row_angles(p, tgv, e, eo, A.lw, g);
+        loss_part += loss_row_angles(p, tgv, e, eo, nq, A.lw, g);
 #pragma unroll
         for (int r = 0; r < 25; ++r) xcur[lane * OP + r] = (r < 19 ? A.lds : 1.f) * g[r];
       }
@@ -642,6 +645,99 @@ __device__ __forceinline__ void fwd_rows(const FusedArgs& A, float* tx, float* t
 }
 
 extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+// Epilogue of a two-layer forward row block: outputs (accumulator layout) -> tile [row][25], then - with the loss fused in -
+// prediction, four-term loss and gradient with respect to the outputs per row (lane r owns row r, lane FR + r converts the
+// target quaternion of row r; the base rows and then the target rows take the place of the outputs in the tile), and the
+// row store.  `to`: FR x 25 floats of LDS owned by the calling wavefront for the duration of the call.
+constexpr int LNV2 = (FR * 25 / 4 + 63) / 64;
+__device__ __forceinline__ void fwd2_outputs_to_tile(const FusedArgs& A, float* to, const f4 (&oacc)[2][FT], int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  // outputs -> tile [row][25]
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int s = 0; s < FT; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = 16 * o + 4 * g + r;
+        if (u < 25 && u < A.nout) to[(16 * s + c) * 25 + u] = oacc[o][s][r];
+        else if (u < 25) to[(16 * s + c) * 25 + u] = 0.f;
+      }
+  fsync();
+}
+// ... the rest of it, from the outputs in the tile
+__device__ __forceinline__ void fwd2_epilogue_rest(const FusedArgs& A, float* to, const f4 (&lvb)[LNV2], const f4 (&lvt)[LNV2],
+                                                   int64_t rb, int lane, float& loss_part) {
+  constexpr int LNV = LNV2;
+  const bool with_loss = A.lbase != nullptr;
+  if (with_loss) {
+    // as in fwd_rows: lane r owns row r, lane FR + r converts the target quaternion of row r; the base rows and then
+    // the target rows take the place of the outputs in the tile
+    static_assert(FR == 32, "lane <-> row map of the loss epilogue");
+    const int rl = lane & (FR - 1);
+    const bool valid = rb * FR + rl < A.Q, lower = lane < FR;
+    float p[25], tgv[25], gr[25];
+#pragma unroll
+    for (int r = 0; r < 25; ++r) p[r] = to[rl * 25 + r];
+    fsync();
+#pragma unroll
+    for (int q = 0; q < LNV; ++q)
+      if (lane + 64 * q < FR * 25 / 4) reinterpret_cast<f4*>(to)[lane + 64 * q] = lvb[q];
+    fsync();
+#pragma unroll
+    for (int r = 0; r < 25; ++r) p[r] = to[rl * 25 + r] + (r < 19 ? A.lds : 1.f) * p[r];
+    fsync();
+#pragma unroll
+    for (int q = 0; q < LNV; ++q)
+      if (lane + 64 * q < FR * 25 / 4) reinterpret_cast<f4*>(to)[lane + 64 * q] = lvt[q];
+    fsync();
+#pragma unroll
+    for (int r = 0; r < 25; ++r) tgv[r] = to[rl * 25 + r];
+    float e[3] = {0.f, 0.f, 0.f}, nq[5];
+    {
+      float q[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) q[cc] = lower ? p[3 + cc] : tgv[3 + cc];
+      if (!valid) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; }
+      q2e_n(q, e, nq);
+    }
+    float eo[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) eo[cc] = __shfl_xor(e[cc], FR, 64);
+    fsync();
+    if (lower && valid) {
+      loss_part += loss_row_angles(p, tgv, e, eo, nq, A.lw, gr);
+#pragma unroll
+      for (int r = 0; r < 25; ++r) to[lane * 25 + r] = (r < 19 ? A.lds : 1.f) * gr[r];
+    }
+    fsync();
+  }
+  {
+    constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;
+    const int rl = lane % FR, part = lane / FR;
+    const int64_t row = rb * FR + rl;
+    if (row < A.Q) {
+      f4* dst = reinterpret_cast<f4*>((with_loss ? A.ldout : A.out) + row * F_LDX) + part * NV;
+#pragma unroll
+      for (int cc = 0; cc < NV; ++cc) {
+        f4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int u = 4 * (part * NV + cc) + e;
+          v[e] = u < 25 ? to[rl * 25 + (u < 25 ? u : 0)] : 0.f;
+        }
+        dst[cc] = v;
+      }
+    }
+  }
+  fsync();
+}
+__device__ __forceinline__ void fwd2_epilogue(const FusedArgs& A, float* to, const f4 (&lvb)[LNV2], const f4 (&lvt)[LNV2],
+                                              const f4 (&oacc)[2][FT], int64_t rb, int lane, float& loss_part) {
+  fwd2_outputs_to_tile(A, to, oacc, lane);
+  fwd2_epilogue_rest(A, to, lvb, lvt, rb, lane, loss_part);
+}
+
 // Two-layer networks in -> H1 -> out with H1 <= 512: ALL forward fragments in the LDS, one copy per CU (workgroups of FW2
 // wavefronts, one per CU): stamps of the kernel below on 28 -> 512 -> 25 showed, per hidden chunk, 1.1 k cycles waiting for
 // the bias fragments, 3.3 k for the 2.0 k of layer-1 products and 4.4 k for the 2.0 k of layer-2 products - fragments
@@ -728,79 +824,7 @@ __global__ __launch_bounds__(64 * FW2) void mlp_fwd2_kernel(const FusedArgs A) {
       chunk_act_only<ACT>(h);
       facc<2, 16>(oacc, wl1, 16 * c1, 0, 16 * ch, lane, [&](int s, int k) { return h.a[k >> 2][s][k & 3]; });
     }
-    // outputs -> tile [row][25]
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int s = 0; s < FT; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int u = 16 * o + 4 * g + r;
-          if (u < 25 && u < A.nout) to[(16 * s + c) * 25 + u] = oacc[o][s][r];
-          else if (u < 25) to[(16 * s + c) * 25 + u] = 0.f;
-        }
-    fsync();
-    if (with_loss) {
-      // as in fwd_rows: lane r owns row r, lane FR + r converts the target quaternion of row r; the base rows and then
-      // the target rows take the place of the outputs in the tile
-      static_assert(FR == 32, "lane <-> row map of the loss epilogue");
-      const int rl = lane & (FR - 1);
-      const bool valid = rb * FR + rl < A.Q, lower = lane < FR;
-      float p[25], tgv[25], gr[25];
-#pragma unroll
-      for (int r = 0; r < 25; ++r) p[r] = to[rl * 25 + r];
-      fsync();
-#pragma unroll
-      for (int q = 0; q < LNV; ++q)
-        if (lane + 64 * q < FR * 25 / 4) reinterpret_cast<f4*>(to)[lane + 64 * q] = lvb[q];
-      fsync();
-#pragma unroll
-      for (int r = 0; r < 25; ++r) p[r] = to[rl * 25 + r] + (r < 19 ? A.lds : 1.f) * p[r];
-      fsync();
-#pragma unroll
-      for (int q = 0; q < LNV; ++q)
-        if (lane + 64 * q < FR * 25 / 4) reinterpret_cast<f4*>(to)[lane + 64 * q] = lvt[q];
-      fsync();
-#pragma unroll
-      for (int r = 0; r < 25; ++r) tgv[r] = to[rl * 25 + r];
-      float e[3] = {0.f, 0.f, 0.f};
-      {
-        float q[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) q[cc] = lower ? p[3 + cc] : tgv[3 + cc];
-        if (!valid) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; }
-        q2e(q, e);
-      }
-      float eo[3];
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) eo[cc] = __shfl_xor(e[cc], FR, 64);
-      fsync();
-      if (lower && valid) {
-        loss_part += loss_row_angles(p, tgv, e, eo, A.lw, gr);
-#pragma unroll
-        for (int r = 0; r < 25; ++r) to[lane * 25 + r] = (r < 19 ? A.lds : 1.f) * gr[r];
-      }
-      fsync();
-    }
-    {
-      constexpr int PARTS = 64 / FR, NV = F_LDX / 4 / PARTS;
-      const int rl = lane % FR, part = lane / FR;
-      const int64_t row = rb * FR + rl;
-      if (row < A.Q) {
-        f4* dst = reinterpret_cast<f4*>((with_loss ? A.ldout : A.out) + row * F_LDX) + part * NV;
-#pragma unroll
-        for (int cc = 0; cc < NV; ++cc) {
-          f4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int u = 4 * (part * NV + cc) + e;
-            v[e] = u < 25 ? to[rl * 25 + (u < 25 ? u : 0)] : 0.f;
-          }
-          dst[cc] = v;
-        }
-      }
-    }
-    fsync();
+    fwd2_epilogue(A, to, lvb, lvt, oacc, rb, lane, loss_part);
   }
   if (with_loss) {
 #pragma unroll

@@ -296,6 +296,10 @@ def test_no_nn_self_consistency(torch_cuda):
     ([28, 48, 80, 25], ["softplus", "relu"], 3001),
     ([18, 64, 64, 6], ["elu", "elu"], 4099),   # the literal network of BASELINE.json configs[2] (fused kernels)
     ([18, 96, 6], ["tanh"], 300),
+    # round 5: mlp_fwd2c_kernel (one hidden chunk per wavefront) with 3 and 5 chunks, several row blocks per workgroup
+    ([28, 192, 25], ["elu"], 3001),
+    ([28, 320, 25], ["elu"], 20011),
+    ([28, 512, 25], ["softplus"], 33333),
 ])
 def test_mlp_forward_backward_vs_torch(torch_cuda, sizes, acts, Q):
     """MFMA GEMM chain against torch (fp64 reference of the same fp32 weights)."""
@@ -330,7 +334,9 @@ def test_mlp_forward_backward_vs_torch(torch_cuda, sizes, acts, Q):
 
 @pytest.mark.parametrize("dims,acts,S,K", [([28, 64, 64, 25], [4, 4, 0], 37, 4), ([28, 512, 25], [4, 0], 41, 3),
                                            ([28, 64, 25], [1, 0], 1, 1), ([28, 40, 40, 25], [2, 2, 0], 300, 4),
-                                           ([28, 96, 96, 25], [4, 4, 0], 10, 2)])
+                                           ([28, 96, 96, 25], [4, 4, 0], 10, 2),
+                                           # round 5: several row blocks per workgroup of mlp_fwd2c_kernel, ragged tail
+                                           ([28, 256, 25], [4, 0], 3001, 4), ([28, 512, 25], [4, 0], 9973, 3)])
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_forward_loss_fused_equals_two_kernels(torch_cuda, dims, acts, S, K, accumulate):
     """kr_mlp_forward_loss (loss in the epilogue of the fused forward kernel; the last shape is one the fused kernels
