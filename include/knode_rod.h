@@ -387,6 +387,15 @@ int kr_train_epoch(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* 
                    int in_pad, const float* base, const float* target_rows, double denom, float* dout, void* ws,
                    double beta1, double beta2, double eps, double weight_decay, int64_t step, double factor,
                    int patience, double threshold, double min_lr, float* loss_log, int phase, int repack, void* stream);
+/* n_epochs consecutive epochs of phase 0 queued by ONE call (the loop of physics_train.py:306-408 on one rank): epoch e runs
+ * as kr_train_epoch(..., step + e, ..., loss_log + e, phase 0, repack for e = 0 only) - same launches, same results bit for
+ * bit; what it saves is the caller's per-epoch host work (a Python / ctypes caller needs longer to issue an epoch than the
+ * GPU to run it: 135 us against 128 at BASELINE cfg3).  loss_log must hold n_epochs floats (or be NULL). */
+int kr_train_epochs(kr_handle* h, int64_t n_epochs, int64_t S, int K, int n_layers, const int32_t* dims, const int32_t* acts,
+                    float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lower, double* sched,
+                    const float* x, int in_pad, const float* base, const float* target_rows, double denom, float* dout, void* ws,
+                    double beta1, double beta2, double eps, double weight_decay, int64_t step, double factor, int patience,
+                    double threshold, double min_lr, float* loss_log, int repack, void* stream);
 
 /* The same loss against pre-gathered targets: the states a training set is scored against never
  * change between epochs, so kr_gather_targets extracts rows[S*K][25] once (y rows at column idx[k],

@@ -728,6 +728,21 @@ int kr_train_epoch(kr_handle* h, int64_t S, int K, int n_layers, const int32_t* 
   return KR_OK;
 }
 
+int kr_train_epochs(kr_handle* h, int64_t n_epochs, int64_t S, int K, int n_layers, const int32_t* dims, const int32_t* acts,
+                    float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lower, double* sched,
+                    const float* x, int in_pad, const float* base, const float* target_rows, double denom, float* dout, void* ws,
+                    double beta1, double beta2, double eps, double weight_decay, int64_t step, double factor, int patience,
+                    double threshold, double min_lr, float* loss_log, int repack, void* stream) {
+  if (n_epochs < 0) { set_error("kr_train_epochs: n_epochs < 0"); return KR_E_ARG; }
+  for (int64_t e = 0; e < n_epochs; ++e) {
+    const int rc = kr_train_epoch(h, S, K, n_layers, dims, acts, params, grads, exp_avg, exp_avg_sq, lower, sched, x, in_pad, base,
+                                  target_rows, denom, dout, ws, beta1, beta2, eps, weight_decay, step + e, factor, patience,
+                                  threshold, min_lr, loss_log ? loss_log + e : nullptr, 0, e == 0 ? repack : 0, stream);
+    if (rc) return rc;
+  }
+  return KR_OK;
+}
+
 int kr_adam_step(kr_handle* h, int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                  const float* lower, double lr, double beta1, double beta2, double eps, double weight_decay,
                  int64_t step, int64_t n_zero, void* stream) {

@@ -98,6 +98,9 @@ _PROTOS = {
     "kr_train_epoch": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp,
                               C.c_double, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double,
                               _int, C.c_double, C.c_double, _vp, _int, _int, _vp]),
+    "kr_train_epochs": (_int, [_vp, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp,
+                               C.c_double, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double,
+                               _int, C.c_double, C.c_double, _vp, _int, _vp]),
     "kr_loss_rows_fwd_bwd": (_int, [_vp, _i64, _int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "kr_estimate_ws_bytes": (C.c_size_t, [_i64, _int]),
     "kr_estimate_state": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),

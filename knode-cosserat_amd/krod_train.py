@@ -361,6 +361,38 @@ class KnodeTrainer:
         self.scheduler.step(val)
         return val
 
+    def run(self, n_epochs):
+        """n_epochs epochs queued by ONE library call (kr_train_epochs) where the single-call epoch applies and no
+        all-reduce sits between its halves; otherwise n_epochs x step().  Nothing waits for the GPU; losses() has the
+        curve.  The per-epoch host work of step() (Python + ctypes: ~135 us) is longer than the epoch on the GPU."""
+        import torch.distributed as dist
+        dp = (self.group is not False and dist.is_available() and dist.is_initialized()
+              and dist.get_world_size(self.group) > 1)
+        ok = (self.fused_epoch and self.native_adam and self.device_plateau and not self.keep_pred and self.Q > 0 and not dp)
+        if not ok or n_epochs < 2:
+            for _ in range(n_epochs):
+                self.step(sync_loss=False)
+            return
+        if not self._fused_epoch():   # first epoch through step(): settles repack / version bookkeeping, may say "unsupported"
+            self.step(sync_loss=False)
+            for _ in range(n_epochs - 1):
+                self.step(sync_loss=False)
+            return
+        n = n_epochs - 1
+        h, sc = self.h, self.scheduler
+        e = sc.steps
+        while e + n > self.loss_log.numel():
+            self.loss_log = torch.cat([self.loss_log, torch.zeros_like(self.loss_log)])
+        kn.check(h.lib.kr_train_epochs(
+            h._h, n, self.S, self.K, self.n, self.dims_c, self.acts_c, kn._ptr(self.flat_p), kn._ptr(self.bucket.flat),
+            kn._ptr(self.exp_avg), kn._ptr(self.exp_avg_sq), kn._ptr(self.lower) if self.clamp_weights else None,
+            kn._ptr(sc.buf), kn._ptr(self.x), self.in_pad, kn._ptr(self.base), kn._ptr(self.target_rows),
+            float(self.steps), kn._ptr(self.dout), kn._ptr(self.ws), self.betas[0], self.betas[1], self.adam_eps,
+            self.weight_decay, self.adam_step + 1, sc.factor, sc.patience, sc.threshold, sc.min_lr,
+            self.loss_log.data_ptr() + 4 * e, 0, kn._stream()))
+        self.adam_step += n
+        sc.steps = self.adam_step
+
     def losses(self):
         """Loss of every epoch taken so far (one device read)."""
         if not self.device_plateau:

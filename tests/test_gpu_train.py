@@ -202,6 +202,35 @@ def test_second_trainer_on_the_same_robot_packs_afresh(torch_cuda):
     assert again == first, (again, first, (tr2.ws.data_ptr(), tr2.flat_p.data_ptr()) == ptrs)
 
 
+@pytest.mark.parametrize("H", [64, 512])
+def test_train_epochs_call_equals_single_epochs(torch_cuda, H):
+    """kr_train_epochs (n epochs queued by one call, KnodeTrainer.run) against n x kr_train_epoch (step()): the same losses
+    and parameters bit for bit - it is the same launches; also across a mix of run() and step() and a loss log that grows."""
+    torch = torch_cuda
+    from krod_train import KnodeTrainer
+    g = load_golden("train_step")
+    traj = torch.tensor(g["traj"], device=DEV)[None].repeat(3, 1, 1, 1)
+    controls = torch.tensor(g["controls"], device=DEV)[None].repeat(3, 1, 1)
+    robs = [make_robot(torch, g if H == 64 else None, H=H) for _ in range(2)]
+    with torch.no_grad():
+        for a, b in zip(robs[0].nn_models.parameters(), robs[1].nn_models.parameters()):
+            b.copy_(a)
+    t1 = KnodeTrainer(robs[0], traj, controls, [3, 5, 7, 9])
+    t2 = KnodeTrainer(robs[1], traj, controls, [3, 5, 7, 9])
+    t2.loss_log = t2.loss_log[:8].clone()  # (forces the log to grow inside run())
+    for _ in range(25):
+        t1.step(sync_loss=False)
+    t2.run(7)
+    t2.step(sync_loss=False)
+    t2.run(17)
+    torch.cuda.synchronize()
+    assert t1.adam_step == t2.adam_step == 25
+    assert t1.losses() == t2.losses()
+    for a, b in zip(robs[0].nn_models.parameters(), robs[1].nn_models.parameters()):
+        assert torch.equal(a, b)
+    assert torch.equal(t1.exp_avg, t2.exp_avg) and torch.equal(t1.exp_avg_sq, t2.exp_avg_sq)
+
+
 def test_native_adam_matches_torch(torch_cuda):
     """kr_adam_step against torch.optim.Adam + clamp over several epochs on the same data, incl. weight decay."""
     torch = torch_cuda
