@@ -323,6 +323,10 @@ def test_bench_two_ranks(torch_cuda):
     assert np.isfinite(dp["loss_first"]) and dp["loss_last"] < dp["loss_first"]
     chk = dp["single_rank_check"]
     assert chk["ok"] and chk["rel_dev_first"] < 2e-5, chk
+    # round 5: the leg explains itself - all-reduce min / median / max, the epoch with and without the collective
+    ar = dp["allreduce_us_stats"]
+    assert ar["n"] == 50 and 0 < ar["min"] <= ar["median"] <= ar["max"]
+    assert dp["epoch_us_with_allreduce"] > 0 and dp["epoch_us_without_allreduce"] > 0
     # strong scaling beside the default weak mode: 1024 rods split over the two ranks
     st = rec["extra"]["strong_scaling"]
     assert st["rods_per_gpu"] == 512 and st["unconverged"] == 0 and st["value"] > 0

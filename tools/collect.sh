@@ -34,7 +34,7 @@ OPS_F32="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_IN
 BENCH="python3 bench.py --no-cpu --no-extra"
 rocprofv3 -L > $out/${tag}_counters.txt 2>&1 || true
 
-# one leg of bench.py's `extra` under the profiler: leg_passes <leg> <pass ...>   (pass: stats fetch write sq sqm ops opsm)
+# one leg of bench.py's `extra` under the profiler: leg_passes <leg> <pass ...>   (pass: stats fetch write sq sqm ops opsm vops64 vops32)
 leg_passes() {
   local leg=$1; shift
   for p in "$@"; do
@@ -47,6 +47,8 @@ leg_passes() {
       sqm)   prof ${leg}_sq 300 --pmc $SQ_MFMA --output-format csv -d $out/${tag}_${leg}_sq -- python3 tools/leg_only.py $leg ;;
       ops)   prof ${leg}_ops 300 --pmc $OPS_F64 --output-format csv -d $out/${tag}_${leg}_ops -- python3 tools/leg_only.py $leg ;;
       opsm)  prof ${leg}_ops 300 --pmc $OPS_MFMA --output-format csv -d $out/${tag}_${leg}_ops -- python3 tools/leg_only.py $leg ;;
+      vops64) prof ${leg}_vops 300 --pmc $OPS_F64 --output-format csv -d $out/${tag}_${leg}_vops -- python3 tools/leg_only.py $leg ;;
+      vops32) prof ${leg}_vops 300 --pmc $OPS_F32 --output-format csv -d $out/${tag}_${leg}_vops -- python3 tools/leg_only.py $leg ;;
     esac
   done
 }
@@ -78,8 +80,8 @@ if want ops; then
 fi
 if want nn; then
   echo "[nn] MLP-on simulate (cfg3 forward), fp64 and fp32: stats, SQ + matrix-pipe counters, executed matrix operations"
-  leg_passes cfg3_nn_f64 stats sqm opsm
-  leg_passes cfg3_nn_f32 stats sqm opsm
+  leg_passes cfg3_nn_f64 stats sqm opsm vops64
+  leg_passes cfg3_nn_f32 stats sqm opsm vops32
 fi
 if want train; then
   echo "[train] training epoch kernels (cfg3: 28-64-64-25, Q = 193 536; cfg4 shard: 28-512-25, Q = 59 392)"

@@ -15,3 +15,12 @@ assert len(a)==len(b)==4, (a,b)
 assert all(abs(x-y)<=1e-4*abs(x) for x,y in zip(a,b)), (a,b)
 print("data-parallel loss curve == single-process loss curve")
 PY
+# Rehearsal of the driver's multi-GPU command on the one-GPU box: bench.py --gpus 4 with the gloo backend (collectives on CPU
+# tensors), four ranks sharing the card (the pool's guard allows 6 processes on one GPU and counts the launcher too: six
+# ranks were killed by it); the driver's own run is --gpus 8 with nccl = RCCL, one rank per GPU.  Same code path: rank-sharded
+# rods, barrier + MAX timing, weak and strong scaling, the cfg4 data-parallel leg with one all-reduce per epoch and the
+# single-rank repeat.  JSON -> gpurun_out/<tag>_rehearsal4.json
+tag=${1:-r05}
+KR_BENCH_BACKEND=gloo timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29533 \
+  bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu > gpurun_out/${tag}_rehearsal4.json 2> gpurun_out/${tag}_rehearsal4.err
+tail -c 1500 gpurun_out/${tag}_rehearsal4.json
