@@ -1737,7 +1737,7 @@ int fused_mlp_backward(int64_t Q, int n_layers, const int32_t* dims, const int32
     const int grid3 = (waves3 + WPB - 1) / WPB;  // wavefronts beyond the row blocks only take part in the sum
     A.nslab = grid3;
     int lrc = KR_OK;
-    if (leave && merged_bwd3()) {  // kr_train_epoch: both passes in one launch, one workgroup per CU
+    if (merged_bwd3()) {  // both passes in one launch, one workgroup per CU (kr_train_epoch and, since round 5, kr_mlp_backward)
       const int wgs = (int)((nblk + BW3 - 1) / BW3 < 256 ? (nblk + BW3 - 1) / BW3 : 256);
       A.nslab = wgs;
       launch_by_act(acts[0], [&](auto act) {
