@@ -830,6 +830,8 @@ int kr_set_mlp(kr_handle* h, int n_layers, const int32_t* dims, const int32_t* a
       P.jobs.src[2 * k + 1] = P.staging + P.src_off[2 * k + 1];
     }
   }
+  // host sources are the caller's to free or overwrite as soon as this call returns: their copies must have left them
+  if (!src_on_device) KR_HIP(hipStreamSynchronize(s));
   const uint32_t total = P.jobs.start[P.jobs.n];
   int grid = (int)((total + 255) / 256);
   if (grid > 1024) grid = 1024;

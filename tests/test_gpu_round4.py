@@ -328,3 +328,58 @@ def test_base_only_storing_sweeps(torch_cuda, act, scale):
     err_off = (np.sqrt(((run(0) - ref) ** 2).sum(axis=(2, 3))) / den).max()
     h.set_option("nn_base_only_store", 1)
     assert err_on < 5e-8 and err_on < 2.0 * max(err_off, 5e-9), (err_on, err_off)
+
+
+# ---- round 5: kr_set_mlp packs on the device -----------------------------------------------------------------------------
+def test_set_mlp_from_device_pointers_equals_host_pointers(torch_cuda):
+    """kr_set_mlp with src_on_device = 1 (one gather launch from the caller's device weights: no device-to-host copy, no
+    allocation when the shape repeats) leaves the same packed network as the host-pointer path: kr_mlp_eval_batch and a
+    simulate with the MLP inside every sweep agree bit for bit; new weights of the same shape reuse the plan, another shape
+    rebuilds it, n_layers = 0 switches the network off and back on."""
+    torch = torch_cuda
+    import ctypes as C
+    import cosserat_oracle as orc
+    import krod_native as kn
+    from cosserat_ode import CosseratRod
+    from knode import setup_robot
+
+    def handle():
+        r = CosseratRod(use_fsolve=True)
+        setup_robot(r)
+        r.N = 40
+        r.compute_intermediate_terms()
+        return r, r._native()
+
+    (r1, h1), (r2, h2) = handle(), handle()
+    x = torch.randn(300, 28, dtype=torch.float64, device=DEV)
+    ctl = torch.as_tensor(orc.batch_sine_controls(16, 6, r1.del_t, 3), device=DEV).contiguous()
+
+    def outputs(h):
+        out = torch.empty((300, 25), dtype=torch.float64, device=DEV)
+        kn.check(h.lib.kr_mlp_eval_batch(h._h, 300, kn._ptr(x), kn._ptr(out), kn.KR_F64, kn._stream()))
+        st = h.new_state(16, torch.float64, n_slots=3)
+        h.init_straight(st[0])
+        G = torch.zeros((16, 6), dtype=torch.float64, device=DEV)
+        tip = torch.empty((16, 6, 3), dtype=torch.float64, device=DEV)
+        h.simulate(ctl, st, G, ring=True, tip=tip, use_nn=True)
+        torch.cuda.synchronize()
+        return out, tip
+
+    for sizes, seed in (([28, 64, 64, 25], 1), ([28, 64, 64, 25], 2), ([28, 96, 25], 3), ([28, 64, 64, 25], 4)):
+        mlp = orc.make_mlp(sizes, "elu", seed=seed)
+        n = len(mlp.weights)
+        h1.set_mlp(mlp.weights, mlp.biases, mlp.acts)                       # host pointers
+        Wd = [torch.as_tensor(np.ascontiguousarray(w, dtype=np.float32), device=DEV) for w in mlp.weights]
+        bd = [torch.as_tensor(np.ascontiguousarray(b, dtype=np.float32), device=DEV) for b in mlp.biases]
+        dims = (C.c_int32 * (n + 1))(*sizes)
+        acts = (C.c_int32 * n)(*[int(a) for a in mlp.acts])
+        Wp = (C.c_void_p * n)(*[w.data_ptr() for w in Wd])
+        bp = (C.c_void_p * n)(*[b.data_ptr() for b in bd])
+        if seed == 4:  # off and on again: the plan of the shape survives
+            kn.check(h2.lib.kr_set_mlp(h2._h, 0, None, None, None, None, 0, kn._stream()))
+        kn.check(h2.lib.kr_set_mlp(h2._h, n, dims, acts, Wp, bp, 1, kn._stream()))    # device pointers
+        o1, t1 = outputs(h1)
+        o2, t2 = outputs(h2)
+        assert torch.equal(o1, o2) and torch.equal(t1, t2), sizes
+        ref = np.stack([orc.mlp_eval(mlp, xi) for xi in x.cpu().numpy()[:40]])
+        assert rel_l2(o1.cpu().numpy()[:40], ref) < 1e-12
