@@ -61,56 +61,18 @@ for dt in (torch.float64, torch.float32):
     print(f"      {str(dt):14s} {s*1e6:7.1f} us/step -> {1024/s/1e6:6.2f} M rod-steps/s (path {path}, unconverged {bad})")
 
 print("cfg3  B=1024, N=100, KNODE MLP 28->64->64->25: one-step-ahead forward+backward over Q=B*T*K rows; forward sim with the MLP on")
+# (the training figures come from the legs bench.py reports - one methodology, one number: bench_legs.train_leg /
+#  mlp_literal_leg, median of HIP-event times after a clock ramp)
+sys.path.insert(0, ROOT)
+import bench_legs as bl
 def train_epoch(M, T, N, kp, layers):
-    rr = robot(N)
-    ctl = orc.batch_sine_controls(M, T, rr.del_t, 1236)
-    o = simulate_batch(rr, ctl, dtype="f32")
-    traj = torch.as_tensor(o["traj"][:, :T], device=dev).float().contiguous()
-    controls = torch.as_tensor(ctl, device=dev).float().contiguous()
-    rob = CosseratRodTorch(dev, layers[0]); setup_robot(rob, "damping"); rob.N = N; rob.compute_intermediate_terms()
-    if len(layers) == 2:
-        mods = [nn.Linear(28, layers[0]), nn.ELU(), nn.Linear(layers[0], layers[1]), nn.ELU(), nn.Linear(layers[1], 25)]
-        for m in mods:
-            if isinstance(m, nn.Linear):
-                rob.non_negative_normal_init(m, 0.01, 0.01); nn.init.normal_(m.bias, 0.0, 0.01)
-        rob.nn_models = nn.ModuleList(mods).to(dev)
-    tr = KnodeTrainer(rob, traj, controls, kp, keep_pred=False)
-    for _ in range(3): tr.step(sync_loss=False)
-    torch.cuda.synchronize(); best = 1e9
-    for _ in range(5):
-        t0 = time.perf_counter()
-        for _ in range(5): tr.step(sync_loss=False)
-        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 5)
-    dims = [28] + layers + [25]
-    return best, tr.Q, 6 * tr.Q * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
-t, Q, fl = train_epoch(1024, 64, 100, [22, 67, 99], [64, 64])
-print(f"      training epoch (fwd + loss + bwd + Adam + clamp), Q={Q} rows: {t*1e6:7.1f} us -> {1024*63/t/1e6:6.1f} M trajectory-steps/s, {fl/t/1e12:5.1f} TFLOP/s fp32 useful")
-# the literal network of BASELINE.json configs[2], 18 -> 64 -> 64 -> 6, as a bare forward + backward over the same Q rows
-import ctypes as C
-import krod_native as kn
-hh = robot(100)._native()
-dims = [18, 64, 64, 6]; Qr = 193536
-gen = torch.Generator(device=dev); gen.manual_seed(0)
-Ws = [torch.randn(dims[k + 1], dims[k], device=dev, generator=gen) * 0.1 for k in range(3)]
-bs = [torch.randn(dims[k + 1], device=dev, generator=gen) * 0.1 for k in range(3)]
-dWs = [torch.zeros_like(w) for w in Ws]; dbs = [torch.zeros_like(b) for b in bs]
-xq = torch.zeros((Qr, 32), device=dev); xq[:, :18] = torch.randn(Qr, 18, device=dev, generator=gen)
-outq = torch.zeros((Qr, 32), device=dev); doutq = torch.zeros((Qr, 32), device=dev); doutq[:, :6] = 1.0
-dims_c = (C.c_int32 * 4)(*dims); acts_c = (C.c_int32 * 3)(4, 4, 0)
-wsq = torch.empty(max(hh.lib.kr_mlp_ws_bytes(3, dims_c, Qr), 16), dtype=torch.uint8, device=dev)
-Wp = (C.c_void_p * 3)(*[w.data_ptr() for w in Ws]); bp = (C.c_void_p * 3)(*[b.data_ptr() for b in bs])
-dWp = (C.c_void_p * 3)(*[w.data_ptr() for w in dWs]); dbp = (C.c_void_p * 3)(*[b.data_ptr() for b in dbs])
-def fb():
-    kn.check(hh.lib.kr_mlp_forward(hh._h, Qr, 3, dims_c, acts_c, Wp, bp, kn._ptr(xq), 32, kn._ptr(outq), kn._ptr(wsq), kn._stream()))
-    kn.check(hh.lib.kr_mlp_backward(hh._h, Qr, 3, dims_c, acts_c, Wp, kn._ptr(xq), 32, kn._ptr(doutq), kn._ptr(wsq), dWp, dbp, kn._stream()))
-for _ in range(3): fb()
-torch.cuda.synchronize(); best = 1e9
-for _ in range(5):
-    t0 = time.perf_counter()
-    for _ in range(5): fb()
-    torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 5)
-fl = 6 * Qr * (18 * 64 + 64 * 64 + 64 * 6)
-print(f"      bare MLP 18->64->64->6 (BASELINE-literal), forward + backward over Q={Qr} rows: {best*1e6:7.1f} us, {fl/best/1e12:5.1f} TFLOP/s fp32 useful")
+    leg = bl.train_leg(torch, 0, M, T, N, kp, layers)
+    return leg["us_per_epoch"] * 1e-6, leg["rows"], leg["roofline"]["achieved"] * 1e12 * leg["us_per_epoch"] * 1e-6, leg
+t, Q, fl, leg = train_epoch(1024, 64, 100, [22, 67, 99], [64, 64])
+print(f"      training epoch (fwd + loss + bwd + Adam + clamp), Q={Q} rows: {t*1e6:7.1f} us (median of {leg['timed_epochs']} epochs after {leg['ramp_epochs']}; {leg['wall_us_per_epoch']:.1f} us wall per epoch queued by kr_train_epochs) "
+      f"-> {1024*63/t/1e6:6.1f} M trajectory-steps/s, {fl/t/1e12:5.1f} TFLOP/s fp32 useful")
+lit = bl.mlp_literal_leg(torch, 0, 193536)
+print(f"      bare MLP 18->64->64->6 (BASELINE-literal), forward + backward over Q=193536 rows: {lit['us_per_fwd_bwd']:7.1f} us, {lit['roofline']['achieved']:5.1f} TFLOP/s fp32 useful")
 rr = robot(100); mlp = orc.make_mlp([28, 64, 64, 25], "elu", seed=7)
 model, params = [], []
 for W, b, a in zip(mlp.weights, mlp.biases, mlp.acts):
@@ -146,13 +108,11 @@ for Bs in (512, 256):  # smaller batches: several wavefronts per rod (kr_mswn_im
 
 print("cfg4  training loop shard: 512 trajectories per GPU (4096 over 8), train_len 30, 28->512->25")
 for N, kp in ((10, [3, 5, 7, 9]), (100, [33, 55, 77, 99])):
-    t, Q, fl = train_epoch(512, 30, N, kp, [512])
+    t, Q, fl, _ = train_epoch(512, 30, N, kp, [512])
     print(f"      N={N:3d}: epoch {t*1e6:7.1f} us (Q={Q} rows) -> {512*29/t/1e6:6.1f} M trajectory-steps/s per GPU, {fl/t/1e12:5.1f} TFLOP/s fp32 useful; + one all-reduce of {28*512+512+512*25+25+1} floats per epoch")
 
 print("cfg5  B=512, N=400, sine tensions; tolerance sweep on the reference fixture sim_n400 (single rod, 12 steps)")
 g = G("sim_n400"); r = robot(400)
-sys.path.insert(0, ROOT)
-import bench_legs as bl
 for dname in ("f64", "f32"):  # the leg bench.py reports as extra.cfg5 (one methodology, one number)
     leg = bl.forward_leg(torch, 0, 512, 400, 60, 30, dname, 1237)
     print(f"      {dname}  {leg['kernel_ms_per_step']*1e3:7.1f} us/step (HIP events; {leg['ms_per_step']*1e3:.1f} wall) -> {leg['value']/1e6:6.2f} M rod-steps/s "
