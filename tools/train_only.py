@@ -28,4 +28,4 @@ if len(layers) == 2:
 tr = KnodeTrainer(rob, traj, controls, kp, keep_pred=False)
 for _ in range(20): tr.step(sync_loss=False)
 torch.cuda.synchronize()
-print("done", tr.Q)
+print("done", tr.Q, "losses", tr.losses()[0], tr.losses()[-1], "lib", __import__("krod_native").LIB_PATH)
