@@ -42,6 +42,10 @@ for name, B, N, T, mk in (("bench workload", 1024, 100, 120, lambda B, T, d: ben
         ref = st.cpu().numpy().copy()
         def err(x):
             return float((np.sqrt(((x[1:] - ref[1:])[..., :25] ** 2).sum(axis=(2, 3))) / np.sqrt((ref[1:][..., :25] ** 2).sum(axis=(2, 3)))).max())
+        def tip_err(x):
+            """the contract's figure: rel L2 of the tip trajectory (slots 12..14 of the last grid point) per rod, worst rod"""
+            d = x[1:, :, -1, 12:15] - ref[1:, :, -1, 12:15]
+            return float((np.sqrt((d ** 2).sum(axis=(0, 2))) / np.sqrt((ref[1:, :, -1, 12:15] ** 2).sum(axis=(0, 2)))).max())
         (a, ba, ta, pa), (b, bb, tb, pb) = res
         print(f"   against a run at tol 1e-11 ({int((status != 0).sum())} unconverged): on {err(a):.2e}, off {err(b):.2e}")
         # fp32 sweeps, both ways, against the same fp64 reference
@@ -54,8 +58,10 @@ for name, B, N, T, mk in (("bench workload", 1024, 100, 120, lambda B, T, d: ben
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 h.simulate(ctl32, st32, G32, ring=False, status=status, use_nn=True)
                 torch.cuda.synchronize(); el32 = (time.perf_counter() - t0) / T
-            e32.append((err(st32.double().cpu().numpy()), el32, int((status != 0).sum())))
-        print(f"   fp32 sweeps: on {e32[0][1]*1e3:.3f} ms/step err {e32[0][0]:.2e} ({e32[0][2]} unconverged), off {e32[1][1]*1e3:.3f} ms/step err {e32[1][0]:.2e} ({e32[1][2]} unconverged)")
+            x32 = st32.double().cpu().numpy()
+            e32.append((err(x32), el32, int((status != 0).sum()), tip_err(x32)))
+        print(f"   fp32 sweeps: on {e32[0][1]*1e3:.3f} ms/step err {e32[0][0]:.2e} TIP {e32[0][3]:.2e} ({e32[0][2]} unconverged), off {e32[1][1]*1e3:.3f} ms/step err {e32[1][0]:.2e} TIP {e32[1][3]:.2e} ({e32[1][2]} unconverged)"
+              f"   [fp64 TIP: on {tip_err(a):.2e} off {tip_err(b):.2e}]")
         # per rod and step, over the whole state (slots 0..24 of every grid point)
         num = np.sqrt(((a[1:] - b[1:])[..., :25] ** 2).sum(axis=(2, 3)))
         den = np.sqrt((b[1:][..., :25] ** 2).sum(axis=(2, 3)))
