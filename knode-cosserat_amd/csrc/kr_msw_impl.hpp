@@ -1413,6 +1413,9 @@ __host__ __device__ inline size_t msw_sim_lds_elems(int N, bool nn = false, int 
   return msw_lds_elems<T, W>(N, nn, hm != 2) + (hm == 0 ? (size_t)2 * N * 12 : 0);
 }
 
+#ifndef KR_MSW_TAPS
+#define KR_MSW_TAPS 3  // taps of the fitted start-value recurrence, MLP off (a compile-time probe: 5 / 7)
+#endif
 template <typename T, bool DIAG, int W, bool NN = false, int OCC = 1, int HM = NN ? 2 : 0>
 __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A, const MlpDev<T> M) {
   static_assert(HM == 2 || !NN, "the MLP-on instantiations keep their history in global memory");
@@ -1449,7 +1452,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   }
   const int ne = R.K * 19;
   T* Xl = L.Xs + R.g0 * 19;
-  MsPred<T, NN ? KR_NN_TAPS : 3> Q;
+  MsPred<T, NN ? KR_NN_TAPS : KR_MSW_TAPS> Q;
   double* img = A.pred_io ? A.pred_io + ((size_t)rod * W + wave) * MS_PRED_ROWS * WAVE : nullptr;
   if (img && A.pred_load) ms_pred_load<T>(Q, img, lane);
   else mswp_init<T>(Q, lane, ne, R.g0, N, P, s0, sp, A.prev_init != nullptr, A.predictor);
@@ -1459,6 +1462,12 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   T Gguess = (wave == 0 && lane < 6) ? A.G[rod * 6 + lane] : T(0);
   const T* ctl = A.ctl + rod * A.T_steps * 4;
   MswNn<T> nn;
+#ifdef KR_MS_STAMPS
+  unsigned long long t_launch;
+  KR_STAMP(t_launch);
+  long long sweeps_total = 0;
+  int sweeps_hist[3] = {0, 0, 0};
+#endif
   __syncthreads();
   for (int64_t t = 0; t < A.T_steps; ++t) {
     T* prv = nullptr;
@@ -1543,10 +1552,25 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       __syncthreads();
     }
     if (wave == 0 && lane == 0 && A.status) A.status[rod * A.T_steps + t] = status;
+#ifdef KR_MS_STAMPS
+    sweeps_total += it;
+    sweeps_hist[it <= 2 ? 0 : it == 3 ? 1 : 2] += 1;
+#endif
     mswp_update<T, W>(Q, order, status, A.predictor, lane, wave, ne, Xl, L.red);
     if (wave == 0 && lane < 6) Gguess = L.Xs[0 * 19 + 7 + lane];
     __syncthreads();  // the storing lanes' leading slots (and Xs) before the next step reads them
   }
+#ifdef KR_MS_STAMPS
+  // diagnostic build (tools/msw_sim_stamps.py): per rod {ticks of the launch, sweep ticks, algebra ticks, -, sweeps, steps with
+  // <= 2 / 3 / >= 4 sweeps} of wavefront 0
+  if (A.dbg && wave == 0 && lane == 0) {
+    unsigned long long te;
+    KR_STAMP(te);
+    unsigned long long* d = A.dbg + rod * 24;
+    d[0] = te - t_launch; d[1] = stamps.sweep; d[2] = stamps.alg; d[4] = (unsigned long long)sweeps_total;
+    d[5] = (unsigned long long)sweeps_hist[0]; d[6] = (unsigned long long)sweeps_hist[1]; d[7] = (unsigned long long)sweeps_hist[2];
+  }
+#endif
   if (wave == 0 && lane < 6) A.G[rod * 6 + lane] = Gguess;
   if (img) {
     Q.kappa = S.kappa;
