@@ -48,6 +48,38 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// 16-byte vector loads / stores through pointers the CALLER knows to be LDS.  The tiles of leading slots are picked by the
+// parity of a time level, and behind such a select the compiler no longer proves the address space: it fell back to
+// flat_load / flat_store (24 + 12 per pair of trips) until the accesses said so themselves.
+#define KR_LDS __attribute__((address_space(3)))
+template <typename T, int NV>
+__device__ __forceinline__ void lds_load_vec(const T* src, T (&v)[NV]) {
+  using V = typename Vec16<T>::type;
+  constexpr int n = Vec16<T>::n;
+  static_assert(NV % n == 0, "vector load needs a multiple of 16 bytes");
+  const KR_LDS V* s = (const KR_LDS V*)src;
+#pragma unroll
+  for (int c = 0; c < NV / n; ++c) {
+    const V x = s[c];
+#pragma unroll
+    for (int e = 0; e < n; ++e) v[c * n + e] = x[e];
+  }
+}
+template <typename T, int NV>
+__device__ __forceinline__ void lds_store_vec(T* dst, const T (&v)[NV]) {
+  using V = typename Vec16<T>::type;
+  constexpr int n = Vec16<T>::n;
+  static_assert(NV % n == 0, "vector store needs a multiple of 16 bytes");
+  KR_LDS V* d = (KR_LDS V*)dst;
+#pragma unroll
+  for (int c = 0; c < NV / n; ++c) {
+    V x;
+#pragma unroll
+    for (int e = 0; e < n; ++e) x[e] = v[c * n + e];
+    d[c] = x;
+  }
+}
+
 #ifdef KR_MS_STAMPS
 struct MsoStats { unsigned long long total = 0, sweeps = 0, merged = 0, quick = 0, chord = 0, rejects = 0, retries = 0, rebuilds = 0, t_sweep = 0, t_alg = 0, t_pred = 0, t_verdict = 0, t_cond = 0, t_fin = 0, t_upd = 0; };
 #endif
@@ -82,16 +114,27 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
   wave_sync();
 
   auto state_ptr = [&](int64_t k) -> T* { return A.states + (A.ring ? k % 3 : k) * A.slot_elems + rod * rod_elems; };
-  // history records of step t (knode.py:74-75) and the leading slots of state t from the states in HBM
+  // The BDF2 history (knode.py:74-75) is kept RAW: two tiles of leading slots (q w v u of every grid point), tile (t & 1)
+  // for the state at time level t.  A lane forms the record it needs - hc1 * newest + hc2 * older, then av / au - itself,
+  // right after the read: 30 instructions that every lane of the wavefront shares, where a precombined record cost the
+  // four verifying lanes the same 30 instructions in a divergent block of their own plus 9 more 16-byte LDS stores and
+  // 6 loads per trip (a wavefront-instruction costs the same with 4 lanes active as with 64, and an LDS store ~13 cycles).
+  T* const lead0 = L.c12;                    // [N][12] states at even time levels
+  const ptrdiff_t lead_d = L.hist - L.c12;  // states at odd time levels: the first 12 N elements of the record area
+  // (offset arithmetic, not a select between two pointers: the compiler turned such selects into a table in scratch)
+  auto lead_of = [&](int64_t t) -> T* { return lead0 + (ptrdiff_t)(t & 1) * lead_d; };
+  // both tiles of step t's history from the states in HBM
   auto rebuild = [&](int64_t t) {
     const T* cur = state_ptr(t);
     const T* prv = t > 0 ? state_ptr(t - 1) : (A.prev_init ? A.prev_init + rod * rod_elems : cur);
+    T* const lc = lead_of(t);
+    T* const lp = lead_of(t - 1);
     for (int j = lane; j < N; j += WAVE) {
       T cv[12], pv[12];
       load_hist_vec<T, 12>(cur + (size_t)j * KR_SLOTS, cv);
       load_hist_vec<T, 12>(prv + (size_t)j * KR_SLOTS, pv);
-      store_vec<T, 12>(L.c12 + (size_t)j * 12, cv);
-      build_hist_cold<T, HS, DIAG>(L.cold, A.hc1, A.hc2, cv, pv, L.hist + (size_t)j * HS);
+      lds_store_vec<T, 12>(lc + (size_t)j * 12, cv);
+      lds_store_vec<T, 12>(lp + (size_t)j * 12, pv);
     }
     wave_sync();
   };
@@ -211,8 +254,28 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
       const int kk = k - lag;
       return s_l + (kk < 0 ? 0 : (kk < len_l ? kk : len_l - 1));
     };
-    T hv[HS];
-    load_hist_vec<T, HS>(L.hist + (size_t)point_of(0) * HS, hv);
+    // History record of this lane's step at grid point j from the two tiles.  The forward-difference lanes work on step
+    // tA (newest state: tile tA & 1), the verifying lanes on step tB = tA - 1 (newest: the other tile; at the grid points
+    // they have not reached yet tile tA & 1 still holds the state at level tB - 1, behind them the state they are
+    // producing).  The tile addresses differ per lane; the arithmetic is the same for all.
+    const T* const lead_n = lead_of(isB ? tB : tA);      // this lane's newest state
+    const T* const lead_o = lead_of(isB ? tB + 1 : tB);  // ... and the one before it (same parity as two levels on)
+    auto hist_at = [&](int j) __attribute__((always_inline)) -> RodHist<T> {
+      T la[12], lb[12], raw[12];
+      lds_load_vec<T, 12>(lead_n + (size_t)j * 12, la);
+      lds_load_vec<T, 12>(lead_o + (size_t)j * 12, lb);
+#pragma unroll
+      for (int c = 0; c < 12; ++c) raw[c] = A.hc1 * la[c] + A.hc2 * lb[c];
+      RodHist<T> h;
+      h.qh = {raw[0], raw[1], raw[2]};
+      h.wh = {raw[3], raw[4], raw[5]};
+      h.vh = {raw[6], raw[7], raw[8]};
+      h.uh = {raw[9], raw[10], raw[11]};
+      h.av = {hk_b[0] * raw[6] + hk_a[0], hk_b[1] * raw[7] + hk_a[1], hk_b[2] * raw[8] + hk_a[2]};  // (Kse + c0 Bse)^-1 (Kse v* - Bse v_h)
+      h.au = {hk_c[0] * raw[9], hk_c[1] * raw[10], hk_c[2] * raw[11]};                                       // -(Kbt + c0 Bbt)^-1 Bbt u_h
+      return h;
+    };
+    RodHist<T> hst = hist_at(point_of(0));
     if (!merged) {
       // plain forward-difference sweep (start-up, rough inputs, after a rejection): the branch-free body of
       // kr_ms_impl.hpp, two grid points per trip so that the scheduler overlaps neighbours; every interval has
@@ -220,8 +283,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
       auto fd_point = [&](int j, T dsl) __attribute__((always_inline)) {
         RodState<T> k1;
         V3<T> v, u;
-        ode_eval<T, DIAG>(Pc, y, hist_from<T, HS>(hv), fc, k1, v, u);
-        load_hist_vec<T, HS>(L.hist + (size_t)(j + 1) * HS, hv);  // (record N - 1 exists and is not used)
+        ode_eval<T, DIAG>(Pc, y, hst, fc, k1, v, u);
+        hst = hist_at(j + 1);  // (grid point N - 1 has leading slots too; its record is not used)
         y = state_axpy(y, dsl, k1);
       };
 #pragma unroll 2
@@ -231,21 +294,18 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
       // one trip of the merged sweep.  FULL: every active lane is inside its interval (no predicates, no clamped
       // indices) - true for the trips MSO_LAG .. sbase - 1, i.e. all but the first and last few.
       const bool lean = A.ring && tB + 4 <= T_steps;  // (the last three states of a call stay complete)
+      T* const lead_w = lead_of(tB + 1);               // the tile the verifying lanes write: state tB + 1 over state tB - 1
       auto trip = [&](int k, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int kk = k - lag;
         const bool live = FULL ? act : (act && kk >= 0 && kk < len_l);
         const int j = FULL ? s_l + kk : point_of(k);
-        // leading slots of the previous state at the verifying lane's grid point: requested now, used after the
-        // arithmetic of this trip (the record written in the previous trip belongs to the grid point before)
-        T old[12];
-        load_hist_vec<T, 12>(L.c12 + (size_t)j * 12, old);
         RodState<T> k1;
         V3<T> v, u;
-        ode_eval<T, DIAG>(Pc, y, hist_from<T, HS>(hv), fc, k1, v, u);
+        ode_eval<T, DIAG>(Pc, y, hst, fc, k1, v, u);
         if (isB && live) {
           // the accepted-to-be state of step tB at grid point j: to HBM; its leading slots replace those of the state
-          // before it in LDS, and the two together are the history record of step tB + 1 at j (knode.py:74-75)
+          // two levels back in LDS (this lane has already read them: its record of grid point j was formed a trip ago)
           T rec[KR_SLOTS];
           record_from(y, v, u, rec);
           T lead[12];
@@ -254,25 +314,16 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
           // On a 3-slot ring nobody reads the states of the call's interior steps - except this kernel when it rolls a
           // step back and the kernel launched behind it when it takes a rod over, and both need only the twelve leading
           // slots of every record plus the full records at the interval starts and at the last grid point (predictor,
-          // z of the last point): interior records of interior steps go out lean (6 instead of 14 stores)
-          if (FULL && lean) store_vec<T, 12>(out_rod + (size_t)j * KR_SLOTS, lead);
-          else store_record(out_rod + (size_t)j * KR_SLOTS, rec);
-          store_vec<T, 12>(L.c12 + (size_t)j * 12, lead);
-          T hrec[HS];
-#pragma unroll
-          for (int c = 0; c < 12; ++c) hrec[c] = A.hc1 * lead[c] + A.hc2 * old[c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            hrec[12 + c] = fma(hk_b[c], hrec[6 + c], hk_a[c]);  // av = (Kse + c0 Bse)^-1 (Kse v* - Bse v_h)
-            hrec[15 + c] = hk_c[c] * hrec[9 + c];               // au = -(Kbt + c0 Bbt)^-1 Bbt u_h
-          }
-          if constexpr (HS > 18) { hrec[18] = T(0); hrec[19] = T(0); }
-          store_vec<T, HS>(L.hist + (size_t)j * HS, hrec);
+          // z of the last point).  The leading slots are what this sweep leaves in its tile: once the step is accepted
+          // the whole tile goes out in one pass of the wavefront (below, 2 x 6 stores from all lanes instead of 6 stores
+          // from four lanes in every trip); interior records of interior steps store nothing here.
+          if (!(FULL && lean)) store_record(out_rod + (size_t)j * KR_SLOTS, rec);
+          lds_store_vec<T, 12>(lead_w + (size_t)j * 12, lead);
         }
-        // history record of the next trip.  A forward-difference lane reads what a verifying lane wrote
-        // MSO_LAG - 1 trips ago (for MSO_LAG = 1: above, in this trip); a verifying lane reads a record it has not
-        // replaced yet.  (FULL: j + 1 <= N - 1 is a valid record even where it lies past the lane's interval.)
-        load_hist_vec<T, HS>(L.hist + (size_t)(FULL ? j + 1 : point_of(k + 1)) * HS, hv);
+        // history record of the next trip.  A forward-difference lane reads the leading slots a verifying lane wrote
+        // MSO_LAG - 1 trips ago (for MSO_LAG = 1: above, in this trip); a verifying lane reads slots it has not
+        // replaced yet.  (FULL: j + 1 <= N - 1 is a valid grid point even where it lies past the lane's interval.)
+        hst = hist_at(FULL ? j + 1 : point_of(k + 1));
         const T dsl = live ? Pc.ds : T(0);  // (a lane outside its range evaluates finite data and adds nothing)
         y = state_axpy(y, dsl, k1);
       };
@@ -378,7 +429,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
           T lead[12];
 #pragma unroll
           for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-          store_vec<T, 12>(L.c12 + (size_t)(N - 1) * 12, lead);
+          lds_store_vec<T, 12>(lead_of(tB + 1) + (size_t)(N - 1) * 12, lead);
           if (A.tip) {
             T* tp = A.tip + (rod * T_steps + tB) * 3;
             tp[0] = y.p.x; tp[1] = y.p.y; tp[2] = y.p.z;
@@ -467,6 +518,14 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
 #endif
       }
       if (accepted) {
+        if (A.ring && tB + 4 <= T_steps) {  // (`lean` of the sweep above) leading slots of the accepted state: tile -> HBM
+          const T* const lt = lead_of(tB + 1);
+          for (int j = lane; j < N; j += WAVE) {
+            T lv[12];
+            lds_load_vec<T, 12>(lt + (size_t)j * 12, lv);
+            store_vec<T, 12>(out_rod + (size_t)j * KR_SLOTS, lv);
+          }
+        }
         if (!belowB && dnB > T(0)) {  // contraction constant where this step first got below the tolerance
           const T floor_dn = T(64) * (sizeof(T) == 8 ? T(2.2e-16) : T(1.2e-7));
           const T kq = fmax((T)dnv, floor_dn) * fast_rcp(dnB * dnB);
