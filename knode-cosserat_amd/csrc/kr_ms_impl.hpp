@@ -312,6 +312,10 @@ struct MsSolveArgs {
   // persistent several-wavefront kernel (kr_msw_impl.hpp): where a storing sweep also leaves the twelve leading slots
   // of every record, [N][12] in LDS (nullptr: nowhere)
   T* lead12 = nullptr;
+  // ... and on a 3-slot ring streams only those twelve slots of an INTERIOR step's interior records to HBM (6 stores per
+  // grid point instead of 14 from the three or four storing lanes of a wavefront): nobody reads the rest - the caller gets
+  // the tips and the last three states, the kernel's own history needs q w v u (as kr_mso_impl.hpp's lean records)
+  bool lean = false;
   bool quick_ok = true;  // option "residual_test": the residual test below may accept a storing sweep
   int prot = 0;          // persistent kernel with the MLP on: sweeps so far (which intervals the p-column lanes serve)
   // fp64 with the MLP on (option "nn_lowp_first"): the FIRST sweep of a step may evaluate the network with the fp32 base

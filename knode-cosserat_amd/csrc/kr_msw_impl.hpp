@@ -903,13 +903,12 @@ __device__ __forceinline__ int msw_newton(const RodConst<T>& Pc, const MswLds<T,
           T rec[KR_SLOTS];
           record_from(y, v, u, rec);
           msw_record_pad<T, NN>(rec);
-          store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
-          if (S.lead12) {
-            T lead[12];
+          T lead[12];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-            store_vec<T, 12>(S.lead12 + (size_t)j * 12, lead);
-          }
+          for (int c = 0; c < 12; ++c) lead[c] = rec[c];
+          if (S.lean) store_vec<T, 12>(S.out_rod + (size_t)j * KR_SLOTS, lead);  // (wave-uniform choice)
+          else store_record(S.out_rod + (size_t)j * KR_SLOTS, rec);
+          if (S.lead12) store_vec<T, 12>(S.lead12 + (size_t)j * 12, lead);
         }
       }
       load_hist_vec<T, HS_LEAN>(hist + (size_t)(j + 1) * HS_LEAN, hv);
@@ -1477,13 +1476,25 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       const T* rc = A.states + (A.ring ? t % 3 : t) * A.slot_elems + rod * rod_elems;
       const T* rp = t > 0 ? A.states + (A.ring ? (t - 1) % 3 : t - 1) * A.slot_elems + rod * rod_elems : sp;
       T* hw = GH ? A.hist_ws + (size_t)rod * N * HS_LEAN : L.hist;
-      for (int j = threadIdx.x; j < N; j += WAVE * W) {
-        T cv[12], pv[12], hv[12];
-        load_hist_vec<T, 12>(rc + (size_t)j * KR_SLOTS, cv);
-        load_hist_vec<T, 12>(rp + (size_t)j * KR_SLOTS, pv);
+      // four grid points per thread at a time, all their loads in flight together: the records come from L2 (this
+      // workgroup has just written them), and one round trip per grid point was most of this loop at N = 400
+      for (int j0 = threadIdx.x; j0 < N; j0 += 4 * WAVE * W) {
+        T cv[4][12], pv[4][12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[k] + A.hc2 * pv[k];
-        store_vec<T, 12>(hw + (size_t)j * HS_LEAN, hv);
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q * WAVE * W;
+          const int jc = j < N ? j : N - 1;  // (clamped: a valid record, not used)
+          load_hist_vec<T, 12>(rc + (size_t)jc * KR_SLOTS, cv[q]);
+          load_hist_vec<T, 12>(rp + (size_t)jc * KR_SLOTS, pv[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q * WAVE * W;
+          T hv[12];
+#pragma unroll
+          for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[q][k] + A.hc2 * pv[q][k];
+          if (j < N) store_vec<T, 12>(hw + (size_t)j * HS_LEAN, hv);
+        }
       }
       const T* cl = rc + (size_t)(N - 1) * KR_SLOTS;  // z of the last grid point is never touched by a sweep
       S.vlast = {cl[6], cl[7], cl[8]};
@@ -1524,6 +1535,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
     S.out_rod = A.states + inx * A.slot_elems + rod * rod_elems;
     S.tip = A.tip ? A.tip + (rod * A.T_steps + t) * 3 : nullptr;
     S.lead12 = prv;
+    S.lean = !NN && A.ring && t + 4 <= A.T_steps;  // (the last three states of a call stay complete)
     int order = Q.next_order;
     int status, it;
     while (true) {
