@@ -316,8 +316,18 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
           // slots of every record plus the full records at the interval starts and at the last grid point (predictor,
           // z of the last point).  The leading slots are what this sweep leaves in its tile: once the step is accepted
           // the whole tile goes out in one pass of the wavefront (below, 2 x 6 stores from all lanes instead of 6 stores
-          // from four lanes in every trip); interior records of interior steps store nothing here.
-          if (!(FULL && lean)) store_record(out_rod + (size_t)j * KR_SLOTS, rec);
+          // from four lanes in every trip); interior records of interior steps store nothing here, all others only
+          // their remaining sixteen slots.
+          if constexpr (FULL) {
+            if (!lean) {  // the rest of the record (p h n m); its leading slots follow with the tile
+              T rest[KR_SLOTS - 12];
+#pragma unroll
+              for (int c = 0; c < KR_SLOTS - 12; ++c) rest[c] = rec[12 + c];
+              store_vec<T, KR_SLOTS - 12>(out_rod + (size_t)j * KR_SLOTS + 12, rest);
+            }
+          } else {
+            store_record(out_rod + (size_t)j * KR_SLOTS, rec);
+          }
           lds_store_vec<T, 12>(lead_w + (size_t)j * 12, lead);
         }
         // history record of the next trip.  A forward-difference lane reads the leading slots a verifying lane wrote
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
 #endif
       }
       if (accepted) {
-        if (A.ring && tB + 4 <= T_steps) {  // (`lean` of the sweep above) leading slots of the accepted state: tile -> HBM
+        {  // leading slots of the accepted state: tile -> HBM, every grid point in one pass of the wavefront
           const T* const lt = lead_of(tB + 1);
           for (int j = lane; j < N; j += WAVE) {
             T lv[12];
