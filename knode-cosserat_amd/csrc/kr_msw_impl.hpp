@@ -1466,10 +1466,14 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
   KR_STAMP(t_launch);
   long long sweeps_total = 0;
   int sweeps_hist[3] = {0, 0, 0};
+  unsigned long long t_hist = 0, t_guess = 0, t_newton = 0, t_upd = 0, tph;
 #endif
   __syncthreads();
   for (int64_t t = 0; t < A.T_steps; ++t) {
     T* prv = nullptr;
+#ifdef KR_MS_STAMPS
+    KR_STAMP(tph);
+#endif
     if constexpr (GL) {
       // BDF2 history (knode.py:74-75) from the two newest states in A.states (this workgroup wrote them: visible after
       // the barrier that ended the step), into the rod's rows of the workspace or its LDS records
@@ -1518,6 +1522,9 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       }
     }
     __syncthreads();
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(t_hist, tph);
+#endif
     V3<T> fconst;
     {
       V3<T> tf{T(0), T(0), T(0)};
@@ -1543,7 +1550,13 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
       wave_sync();
       if (wave == 0 && order <= 0 && lane < 6) L.Xs[0 * 19 + 7 + lane] = Gguess;  // caller's guess (knode.py:67,89)
       __syncthreads();
+#ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(t_guess, tph);
+#endif
       status = msw_newton<T, DIAG, W, NN, OCC - 1>(Pc, L, R, lane, fconst, S, it, stamps, hist, nn);
+#ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(t_newton, tph);
+#endif
       if (status == KR_ST_CONVERGED || order == 0) break;
       order = 0;  // the predicted start did not converge: redo the step from the reference's warm start
       __syncthreads();
@@ -1571,6 +1584,9 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
     mswp_update<T, W>(Q, order, status, A.predictor, lane, wave, ne, Xl, L.red);
     if (wave == 0 && lane < 6) Gguess = L.Xs[0 * 19 + 7 + lane];
     __syncthreads();  // the storing lanes' leading slots (and Xs) before the next step reads them
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(t_upd, tph);
+#endif
   }
 #ifdef KR_MS_STAMPS
   // diagnostic build (tools/msw_sim_stamps.py): per rod {ticks of the launch, sweep ticks, algebra ticks, -, sweeps, steps with
@@ -1581,6 +1597,8 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
     unsigned long long* d = A.dbg + rod * 24;
     d[0] = te - t_launch; d[1] = stamps.sweep; d[2] = stamps.alg; d[4] = (unsigned long long)sweeps_total;
     d[5] = (unsigned long long)sweeps_hist[0]; d[6] = (unsigned long long)sweeps_hist[1]; d[7] = (unsigned long long)sweeps_hist[2];
+    d[8] = stamps.a1; d[9] = stamps.a2; d[10] = stamps.a3; d[11] = stamps.a4;  // condensation: local chains, barrier, boundary chain, rest
+    d[12] = t_hist; d[13] = t_guess; d[14] = t_newton; d[15] = t_upd;           // step loop: history build, start values, Newton, predictor update
   }
 #endif
   if (wave == 0 && lane < 6) A.G[rod * 6 + lane] = Gguess;

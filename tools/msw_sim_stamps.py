@@ -33,3 +33,5 @@ print(f"N={N} B={B} W={h.get_option('last_waves_per_rod')} path {h.get_option('l
 print(f"  ticks per step: total mean {tot.mean()/T:.0f} max {tot.max()/T:.0f} | sweep {sw.mean()/T:.0f} algebra {al.mean()/T:.0f} | sweeps per step mean {its.mean()/T:.3f}, slowest rod {its.max()/T:.3f}")
 its_sum = max(its.sum(), 1.0)
 print(f"  steps with <= 2 / 3 / >= 4 sweeps: {d[:,5].sum()/(B*T):.3f} / {d[:,6].sum()/(B*T):.3f} / {d[:,7].sum()/(B*T):.3f}; per sweep {sw.sum()/its_sum:.0f} ticks, algebra per sweep {al.sum()/its_sum:.0f}")
+print(f"  condensation per step: local chains {d[:,8].mean()/T:.0f}, barrier {d[:,9].mean()/T:.0f}, boundary chain {d[:,10].mean()/T:.0f}, solve + back-substitution + p rows + norms + decisions {d[:,11].mean()/T:.0f}")
+print(f"  step loop per step: history build {d[:,12].mean()/T:.0f}, start values {d[:,13].mean()/T:.0f}, Newton (sweeps + algebra + residual tests) {d[:,14].mean()/T:.0f}, predictor update {d[:,15].mean()/T:.0f}")
