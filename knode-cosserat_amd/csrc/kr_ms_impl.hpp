@@ -1380,6 +1380,10 @@ __device__ __forceinline__ void ms_pred_update(MsPred<T, NC>& Q, int order, int 
     // until the jump has left the stencil; fresh random controls every step stay at order 0, which
     // is the reference's warm start, knode.py:89)
     {
+#ifdef KR_MS_STAMPS
+      unsigned long long tpu;
+      KR_STAMP(tpu);
+#endif
       // (while the fitted recurrence below is in use and predicts to better than 1e-3 the polynomial orders
       // are not evaluated at all: their errors would only be compared with a much smaller one)
       const bool poly_eval = !(order == MS_ORDER_LP && Q.lp_good);
@@ -1415,6 +1419,9 @@ __device__ __forceinline__ void ms_pred_update(MsPred<T, NC>& Q, int order, int 
         }
       }
       const float em_lp = wave_max_nonneg(err_lp);
+#ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(stamps.a1, tpu);  // errors of the predictors in use
+#endif
       const bool lp_tested = Q.lp_have;
       // a fit that just predicted to better than 1e-3 is kept for up to four steps (its test on the following
       // steps stays out of sample); otherwise refit now
@@ -1445,6 +1452,9 @@ __device__ __forceinline__ void ms_pred_update(MsPred<T, NC>& Q, int order, int 
           Q.lp_have = true;
         }
       }
+#ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(stamps.a2, tpu);  // refit (every fourth step)
+#endif
       const int pmax = Q.avail < predictor ? Q.avail : (predictor < MS_HLEV ? predictor : MS_HLEV - 1);  // orders the history supported
       float em[MS_HLEV];
 #pragma unroll
@@ -1471,6 +1481,9 @@ __device__ __forceinline__ void ms_pred_update(MsPred<T, NC>& Q, int order, int 
         Q.next_order = 0;
         Q.avail = -1;  // becomes 0 below
       }
+#ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(stamps.a3, tpu);  // choice of the next order
+#endif
     }
 #pragma unroll
     for (int q = 0; q < MS_EPL; ++q) {

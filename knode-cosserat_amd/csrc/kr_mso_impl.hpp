@@ -81,7 +81,7 @@ __device__ __forceinline__ void lds_store_vec(T* dst, const T (&v)[NV]) {
 }
 
 #ifdef KR_MS_STAMPS
-struct MsoStats { unsigned long long total = 0, sweeps = 0, merged = 0, quick = 0, chord = 0, rejects = 0, retries = 0, rebuilds = 0, t_sweep = 0, t_alg = 0, t_pred = 0, t_verdict = 0, t_cond = 0, t_fin = 0, t_upd = 0; };
+struct MsoStats { unsigned long long total = 0, sweeps = 0, merged = 0, quick = 0, chord = 0, rejects = 0, retries = 0, rebuilds = 0, t_sweep = 0, t_alg = 0, t_pred = 0, t_verdict = 0, t_cond = 0, t_fin = 0, t_upd = 0, t_v1 = 0, t_v2 = 0, t_c1 = 0, t_c2 = 0, t_copy = 0; };
 #endif
 
 // OCC: workgroups per CU the register allocation leaves room for.  OCC = 2 (fp32, batches beyond one rod per SIMD)
@@ -447,6 +447,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
         }
       }
       wave_sync_lds();
+#ifdef KR_MS_STAMPS
+      unsigned long long tv;
+      { KR_STAMP(tv); st.t_v1 += tv - tq; }  // end states of the verifying lanes, record of the last grid point
+#endif
       // residual of the sweep: interface jumps E_g - Y_{g+1} and the tip condition, one component per lane
       float rn = 0.f;
       if (lane < 3 * MS_YP) {
@@ -459,6 +463,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
         rn = update_ratio(L.cold[CD_FTIP + k] - e, e);
       }
       rn = wave_max_nonneg(rn);
+#ifdef KR_MS_STAMPS
+      KR_STAMP_ADD(st.t_v2, tv);  // residual norm
+#endif
       const float est = ampB * rn;
       // residual test (kr_ms_impl.hpp: audited factor 256 on the measured update / residual ratio)
       bool accepted = A.residual_test != 0 && ampB > 0.f && T(256) * (T)est <= tol;
@@ -629,6 +636,10 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
       }
       wave_sync_lds();
     }
+#ifdef KR_MS_STAMPS
+    unsigned long long tc;
+    { KR_STAMP(tc); st.t_c1 += tc - tq2; }  // end states, residual norm, forward-difference columns through Es
+#endif
     dYb = XB;
     {
       const T c0 = Es[0 * MS_YP + r] - Xs[1 * MS_YP + r];
@@ -679,6 +690,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
       }
       wave_sync_lds();
     }
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(st.t_c2, tc);  // condensation chain
+#endif
     {
       T a6[6][7];
 #pragma unroll
@@ -762,6 +776,9 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
       // hand step tA to the verifying lanes and move the forward-difference lanes on to step tA + 1
       for (int e = lane; e < MS_NE; e += WAVE) XsB[e] = Xs[e];
       wave_sync_lds();
+#ifdef KR_MS_STAMPS
+      { unsigned long long t_; KR_STAMP(t_); st.t_copy += t_ - tq; }
+#endif
       dnB = dn; ampB = amp; belowB = below; itB = it; orderB = order;
       if (!pred_skip) ms_pred_update<T>(Q, order, KR_ST_CONVERGED, A.predictor, lane, XsB, stamps);
 #ifdef KR_MS_STAMPS
@@ -804,6 +821,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
     dd[5] = st.merged; dd[6] = st.quick; dd[7] = st.chord; dd[8] = st.rejects; dd[9] = st.retries; dd[10] = st.rebuilds;
     dd[11] = (unsigned long long)resume_at;
     dd[12] = st.t_verdict; dd[13] = st.t_cond; dd[14] = st.t_fin; dd[15] = st.t_upd;
+    dd[16] = stamps.a1; dd[17] = stamps.a2; dd[18] = stamps.a3; dd[19] = st.t_v1; dd[20] = st.t_v2; dd[21] = st.t_c1; dd[22] = st.t_c2; dd[23] = st.t_copy;
   }
 #endif
 }

@@ -38,3 +38,7 @@ names = ["total", "t_sweep", "t_alg", "t_pred", "sweeps", "merged", "quick", "ch
 for k, n in enumerate(names):
     print(f"  {n:10s} per step: mean {d[:, k].mean() / T:10.3f}  max {d[:, k].max() / T:10.3f}")
 print("  ticks per sweep:", d[:, 1].sum() / d[:, 4].sum(), " per condensation:", d[:, 2].sum() / d[:, 4].sum(), " tick rate MHz", d[:, 0].max() / el / 1e6)
+ex = ["pred: errors of the predictors in use", "pred: refit", "pred: choice of the order", "verdict: end states + last record", "verdict: residual norm",
+      "cond: columns through Es + residual norm", "cond: chain", "hand-over: copy of the unknowns"]
+for k, n in enumerate(ex):
+    print(f"  {n:44s} per step: mean {d[:, 16 + k].mean() / T:9.1f}")
