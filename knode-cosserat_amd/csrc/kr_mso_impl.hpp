@@ -31,7 +31,13 @@
 namespace kr {
 
 constexpr int MSO_B0 = 7 + 17 * (MS_P - 1);  // 58: first of the four lanes that re-integrate the step under verification
-constexpr int MSO_LAG = 1;  // grid points the verifying lanes run ahead of the lanes that consume their records (2: 3 % slower)
+#ifndef KR_MSO_LAG
+#define KR_MSO_LAG 1
+#endif
+// grid points the verifying lanes run ahead of the lanes that consume their records.  2 (-DKR_MSO_LAG=2: a compile-time probe)
+// lets the next trip's tile reads go out under this trip's arithmetic - measured 40.8 M against 42.1 M rod-steps/s (one more
+// trip per sweep, and the pinned hand-over keeps the compiler from pairing trips)
+constexpr int MSO_LAG = KR_MSO_LAG;
 static_assert(MSO_B0 + MS_P <= WAVE, "the verifying lanes must fit beside the forward-difference lanes");
 
 template <typename T, int HS>
@@ -260,10 +266,8 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
     // producing).  The tile addresses differ per lane; the arithmetic is the same for all.
     const T* const lead_n = lead_of(isB ? tB : tA);      // this lane's newest state
     const T* const lead_o = lead_of(isB ? tB + 1 : tB);  // ... and the one before it (same parity as two levels on)
-    auto hist_at = [&](int j) __attribute__((always_inline)) -> RodHist<T> {
-      T la[12], lb[12], raw[12];
-      lds_load_vec<T, 12>(lead_n + (size_t)j * 12, la);
-      lds_load_vec<T, 12>(lead_o + (size_t)j * 12, lb);
+    auto hist_form = [&](const T (&la)[12], const T (&lb)[12]) __attribute__((always_inline)) -> RodHist<T> {
+      T raw[12];
 #pragma unroll
       for (int c = 0; c < 12; ++c) raw[c] = A.hc1 * la[c] + A.hc2 * lb[c];
       RodHist<T> h;
@@ -274,6 +278,12 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
       h.av = {hk_b[0] * raw[6] + hk_a[0], hk_b[1] * raw[7] + hk_a[1], hk_b[2] * raw[8] + hk_a[2]};  // (Kse + c0 Bse)^-1 (Kse v* - Bse v_h)
       h.au = {hk_c[0] * raw[9], hk_c[1] * raw[10], hk_c[2] * raw[11]};                                       // -(Kbt + c0 Bbt)^-1 Bbt u_h
       return h;
+    };
+    auto hist_at = [&](int j) __attribute__((always_inline)) -> RodHist<T> {
+      T la[12], lb[12];
+      lds_load_vec<T, 12>(lead_n + (size_t)j * 12, la);
+      lds_load_vec<T, 12>(lead_o + (size_t)j * 12, lb);
+      return hist_form(la, lb);
     };
     RodHist<T> hst = hist_at(point_of(0));
     if (!merged) {
@@ -300,9 +310,24 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
         const int kk = k - lag;
         const bool live = FULL ? act : (act && kk >= 0 && kk < len_l);
         const int j = FULL ? s_l + kk : point_of(k);
+        // MSO_LAG >= 2: what the next trip reads was written a trip ago - requested now, under the arithmetic of this one
+        T la[12], lb[12];
+        if constexpr (MSO_LAG >= 2) {
+          const int jn = FULL ? j + 1 : point_of(k + 1);
+          lds_load_vec<T, 12>(lead_n + (size_t)jn * 12, la);
+          lds_load_vec<T, 12>(lead_o + (size_t)jn * 12, lb);
+        }
         RodState<T> k1;
         V3<T> v, u;
         ode_eval<T, DIAG>(Pc, y, hst, fc, k1, v, u);
+        // (formed in front of the verifying lanes' block: behind it the wait for the reads would also wait for its stores)
+        if constexpr (MSO_LAG >= 2) {
+          hst = hist_form(la, lb);
+          // (pinned: the compiler otherwise sinks the arithmetic - and with it the wait - behind the block)
+          asm volatile("" : "+v"(hst.qh.x), "+v"(hst.qh.y), "+v"(hst.qh.z), "+v"(hst.wh.x), "+v"(hst.wh.y), "+v"(hst.wh.z));
+          asm volatile("" : "+v"(hst.vh.x), "+v"(hst.vh.y), "+v"(hst.vh.z), "+v"(hst.uh.x), "+v"(hst.uh.y), "+v"(hst.uh.z));
+          asm volatile("" : "+v"(hst.av.x), "+v"(hst.av.y), "+v"(hst.av.z), "+v"(hst.au.x), "+v"(hst.au.y), "+v"(hst.au.z));
+        }
         if (isB && live) {
           // the accepted-to-be state of step tB at grid point j: to HBM; its leading slots replace those of the state
           // two levels back in LDS (this lane has already read them: its record of grid point j was formed a trip ago)
@@ -333,7 +358,7 @@ __global__ __launch_bounds__(WAVE * MS_WPB, OCC) void mso_sim_kernel(const RodCo
         // history record of the next trip.  A forward-difference lane reads the leading slots a verifying lane wrote
         // MSO_LAG - 1 trips ago (for MSO_LAG = 1: above, in this trip); a verifying lane reads slots it has not
         // replaced yet.  (FULL: j + 1 <= N - 1 is a valid grid point even where it lies past the lane's interval.)
-        hst = hist_at(FULL ? j + 1 : point_of(k + 1));
+        if constexpr (MSO_LAG < 2) hst = hist_at(FULL ? j + 1 : point_of(k + 1));
         const T dsl = live ? Pc.ds : T(0);  // (a lane outside its range evaluates finite data and adds nothing)
         y = state_axpy(y, dsl, k1);
       };
