@@ -283,8 +283,8 @@ int kr_step_batch(kr_handle* h, int64_t B, int scheme, const void* state_prev, c
  * writes states[t+1]; if ring != 0, `states` holds only 3 slots used
  * cyclically (slot (t+1)%3) for tip-only runs: on return they hold the complete
  * last three states of the call (states T, T-1, T-2); what passes through them
- * before that is scratch of the library (the overlapped kernel writes interior
- * states only as far as it may have to re-read them).  tip[B][T][3] may be NULL.
+ * before that is scratch of the library (the persistent kernels write interior
+ * states only as far as they may have to re-read them: the twelve leading slots).  tip[B][T][3] may be NULL.
  * status[B][T] may be NULL.  Replaces knode.simulate (knode.py:55-102).
  * state_prev_init: NULL = the reference's start (y_prev = y before the first
  * step, knode.py:65-66); otherwise the packed state one step before states[0],
