@@ -11,15 +11,19 @@
 //     lanes 58..61   re-integrate step t from x1(t), one lane per sub-interval, and stream the state out
 // The start values of step t + 1 only need the UNKNOWNS of step t (known after its Newton update), and its BDF2
 // history record at grid point j only needs the state of step t at j - so the verifying lanes run one grid point
-// ahead, form the history record of the next step in place (LDS) and the forward-difference lanes pick it up at the
-// end of the same trip, for their next one.  Per time step that leaves one sweep and one condensation; the discrete equations, the Newton
-// iteration, the stopping rule and the stored states are those of kr_ms_impl.hpp (cosserat_ode.py:188-213 inside
-// knode.py:70-100).
+// ahead and leave the twelve leading slots (q w v u) of every grid point they produce in an LDS tile; the
+// forward-difference lanes pick them up at the end of the same trip and form the history record of their next grid point
+// themselves (round 5: two raw tiles, time level t in tile t & 1 - a precombined record cost the four verifying lanes a
+// divergent block of 30 fp64 instructions, 15 LDS stores and 6 LDS loads per trip, and a store from a lone wavefront is
+// the most expensive instruction there is: LABBOOK, "what a store costs a lone wavefront").  Per time step that leaves
+// one sweep and one condensation; the discrete equations, the Newton iteration, the stopping rule and the stored states
+// are those of kr_ms_impl.hpp (cosserat_ode.py:188-213 inside knode.py:70-100).
 //
 // Acceptance of step t is still a measured quantity of a sweep at the stored unknowns: the residual test, else the
 // chord update through the factors of step t's last condensation (which are only overwritten afterwards).  If
-// neither accepts, the Jacobian work for step t + 1 is thrown away, the chord update is applied, the history is
-// rebuilt from the two previous states in HBM and step t continues with plain forward-difference sweeps.
+// neither accepts, the Jacobian work for step t + 1 is thrown away, the chord update is applied, the tiles are
+// rebuilt from the two previous states in HBM (an accepted state's leading slots go there in one pass of the wavefront,
+// the rest of a record that must be complete during its trip) and step t continues with plain forward-difference sweeps.
 // Everything beyond that - a step that does not converge from the predicted or from the warm start - is left to
 // kr_ms_impl.hpp's kernel, launched behind this one: a rod that gives up writes the step it stopped at to
 // SimArgs::resume and the second kernel resumes there with the full ladder (warm start, damped single shooting).
