@@ -55,6 +55,8 @@ def kernel_label(h):
     path = h.get_option("last_sim_path")
     wpr = h.get_option("last_waves_per_rod")
     if wpr > 1:
+        if path == 2 and h.get_option("last_overlap"):
+            return f"kr::mswo_sim_kernel (persistent, overlapped steps, {wpr} wavefronts per rod)"
         return (f"kr::msw_sim_kernel (persistent, {wpr} wavefronts per rod)" if path == 2
                 else f"kr::msw_step_kernel ({wpr} wavefronts per rod)")
     if path == 2 and h.get_option("last_overlap"):

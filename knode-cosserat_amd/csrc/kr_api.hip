@@ -420,6 +420,7 @@ int kr_create(const kr_params* p, int device, kr_handle** out) {
   if (const char* e = std::getenv("KR_PREDICTOR")) h->predictor = std::atoi(e);
   if (const char* e = std::getenv("KR_PERSISTENT")) h->persistent = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_OVERLAP")) h->overlap = std::atoi(e) ? 1 : 0;
+  if (const char* e = std::getenv("KR_MSW_OVERLAP")) h->msw_overlap = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_RESIDUAL_TEST")) h->residual_test = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_NN_LOWP_FIRST")) h->nn_lowp_first = std::atoi(e) ? 1 : 0;
   if (const char* e = std::getenv("KR_NN_BASE_ONLY_STORE")) h->nn_base_only_store = std::atoi(e) ? 1 : 0;
@@ -458,6 +459,8 @@ int kr_set_option(kr_handle* h, const char* name, int value) {
     h->predictor = value;
   } else if (n == "overlap") {
     h->overlap = value ? 1 : 0;
+  } else if (n == "msw_overlap") {
+    h->msw_overlap = value ? 1 : 0;
   } else if (n == "residual_test") {
     h->residual_test = value ? 1 : 0;
   } else if (n == "nn_base_only_store") {
@@ -488,6 +491,7 @@ int kr_get_option(kr_handle* h, const char* name, int* value) {
   else if (n == "waves_per_rod") *value = h->waves_per_rod;
   else if (n == "last_waves_per_rod") *value = h->last_waves_per_rod;
   else if (n == "overlap") *value = h->overlap;
+  else if (n == "msw_overlap") *value = h->msw_overlap;
   else if (n == "residual_test") *value = h->residual_test;
   else if (n == "nn_lowp_first") *value = h->nn_lowp_first;
   else if (n == "nn_base_only_store") *value = h->nn_base_only_store;
