@@ -322,7 +322,8 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
           T lead[12];
 #pragma unroll
           for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-          if (!(FULL && lean)) store_record(out_rod + (size_t)j * KR_SLOTS, rec);
+          // (no take-over kernel reads interval-start records here: lean steps store nothing at all in a trip)
+          if (!lean) store_record(out_rod + (size_t)j * KR_SLOTS, rec);
           lds_store_vec<T, 12>(tnew + (size_t)j * 12, lead);
         }
         hist_at(FULL ? j + 1 : point_of(k + 1), hv);
@@ -359,11 +360,11 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
         if (gB == P - 1) {  // the last grid point: y from the sweep, z untouched
           T rec[KR_SLOTS];
           record_from(y, S.vlast, S.ulast, rec);
-          store_record(out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+          if (!(A.ring && tB + 4 <= T_steps)) store_record(out_rod + (size_t)(N - 1) * KR_SLOTS, rec);  // (`lean` of the sweep)
           T lead[12];
 #pragma unroll
           for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-          store_vec<T, 12>(tile(tB + 1) + (size_t)(N - 1) * 12, lead);
+          lds_store_vec<T, 12>(tile(tB + 1) + (size_t)(N - 1) * 12, lead);
           if (A.tip) {
             T* tp = A.tip + (rod * T_steps + tB) * 3;
             tp[0] = y.p.x; tp[1] = y.p.y; tp[2] = y.p.z;
