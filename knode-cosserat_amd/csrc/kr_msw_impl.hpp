@@ -678,6 +678,10 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
       }
       solve6(a6, d);
     }
+#ifdef KR_MS_STAMPS
+    unsigned long long tb = ta;
+    KR_STAMP_ADD(stamps.prep, tb);   // 6 x 6 solve
+#endif
     // ---- updates of rows 3..18 of every unknown ---------------------------------------------------------------
     const T dd0 = kp == 0 ? T(1) : kp == 1 ? d[1] : kp == 2 ? d[3] : d[5];
     const T dd1 = kp == 0 ? d[0] : kp == 1 ? d[2] : kp == 2 ? d[4] : T(0);
@@ -718,6 +722,9 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
       }
     }
     msw_lds_barrier();
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.total, tb);  // back-substitution + barrier
+#endif
     // ---- p rows: dY_{g+1}[p] = sum_{i<=g} (c_i[p] + A_i[p, :] dY_i[3:]) ------------------------------------------
     if (lane < 3 * R.K) {
       const int k = lane / 3, prow = lane - 3 * k;
@@ -742,6 +749,9 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
       L.sp[g * 4 + prow] = s + s2;
     }
     msw_lds_barrier();
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.osum, tb);   // p rows + barrier
+#endif
     // ---- scaled update norm over this wavefront's unknowns, then over the rod -----------------------------------
     float dnf = 0.f;
     T updP = T(0), xsP = T(0);
@@ -781,6 +791,9 @@ __device__ __forceinline__ void msw_condense(const MswLds<T, W>& L, const MswRol
       dnf = fmaxf(dnf, update_ratio(updG, xsG));
     }
     msw_max2<W>(dnf, res_local, redf, wave, lane);
+#ifdef KR_MS_STAMPS
+    KR_STAMP_ADD(stamps.retries, tb);  // norms + reduction over the rod
+#endif
   U.dnf = dnf; U.res_local = res_local;
   U.updP = updP; U.xsP = xsP; U.updG = updG; U.xsG = xsG;
 #pragma unroll
@@ -1599,6 +1612,7 @@ __global__ __launch_bounds__(WAVE * W, OCC) void msw_sim_kernel(const RodConst<T
     d[5] = (unsigned long long)sweeps_hist[0]; d[6] = (unsigned long long)sweeps_hist[1]; d[7] = (unsigned long long)sweeps_hist[2];
     d[8] = stamps.a1; d[9] = stamps.a2; d[10] = stamps.a3; d[11] = stamps.a4;  // condensation: local chains, barrier, boundary chain, rest
     d[12] = t_hist; d[13] = t_guess; d[14] = t_newton; d[15] = t_upd;           // step loop: history build, start values, Newton, predictor update
+    d[16] = stamps.prep; d[17] = stamps.total; d[18] = stamps.osum; d[19] = stamps.retries;  // inside "rest": solve, back-substitution, p rows, norms
   }
 #endif
   if (wave == 0 && lane < 6) A.G[rod * 6 + lane] = Gguess;

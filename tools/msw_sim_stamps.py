@@ -35,3 +35,4 @@ its_sum = max(its.sum(), 1.0)
 print(f"  steps with <= 2 / 3 / >= 4 sweeps: {d[:,5].sum()/(B*T):.3f} / {d[:,6].sum()/(B*T):.3f} / {d[:,7].sum()/(B*T):.3f}; per sweep {sw.sum()/its_sum:.0f} ticks, algebra per sweep {al.sum()/its_sum:.0f}")
 print(f"  condensation per step: local chains {d[:,8].mean()/T:.0f}, barrier {d[:,9].mean()/T:.0f}, boundary chain {d[:,10].mean()/T:.0f}, solve + back-substitution + p rows + norms + decisions {d[:,11].mean()/T:.0f}")
 print(f"  step loop per step: history build {d[:,12].mean()/T:.0f}, start values {d[:,13].mean()/T:.0f}, Newton (sweeps + algebra + residual tests) {d[:,14].mean()/T:.0f}, predictor update {d[:,15].mean()/T:.0f}")
+print(f"  inside the last figure of the condensation: 6 x 6 solve {d[:,16].mean()/T:.0f}, back-substitution + barrier {d[:,17].mean()/T:.0f}, p rows + barrier {d[:,18].mean()/T:.0f}, norms + reduction over the rod {d[:,19].mean()/T:.0f}")
