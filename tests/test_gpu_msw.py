@@ -424,3 +424,77 @@ def test_auto_choice(torch_cuda, monkeypatch):
     h = make_robot(None, 20)._native()
     run(h, 4)
     assert h.get_option("last_sim_path") == 2 and h.get_option("last_waves_per_rod") == 1
+
+
+@pytest.mark.parametrize("N,kind", [(100, "sine"), (64, "random"), (40, "jumps")])
+def test_overlapped_steps_on_several_wavefronts(torch_cuda, waves_persistent, N, kind):
+    """kr_mswo_impl.hpp (option "msw_overlap", default on, fp64): the verifying sweep of step t on spare lanes of the
+    Jacobian sweep of step t + 1, on 2 or 4 wavefronts per rod.  Same tips, states and status as the plain persistent
+    form on smooth and on rough inputs (fresh random tensions every step: rejected verdicts, chord checks, roll-backs),
+    as a trajectory, in a 3-slot ring and advanced by three calls; and the oracle's tips on the smooth case.
+    Reference: knode.py:55-102 (what both kernels replace)."""
+    torch = torch_cuda
+    import cosserat_oracle as orc
+    W = waves_persistent
+    r = make_robot(None, N)
+    h = r._native()
+    dt = torch.float64
+    B, T = 12, 24
+    rng = np.random.default_rng(N)
+    if kind == "sine":
+        ctl_np = orc.batch_sine_controls(B, T, r.del_t, 5)
+    elif kind == "random":
+        ctl_np = 5.0 + 5.0 * rng.uniform(size=(B, T, 4))
+    else:
+        ctl_np = np.full((B, T, 4), 5.0)
+        for b in range(B):
+            ctl_np[b, rng.integers(1, T):, rng.integers(0, 4)] += rng.uniform(-2, 2)
+    ctl = torch.as_tensor(ctl_np, device=DEV).contiguous()
+
+    def run(overlap, mode):
+        h.set_option("msw_overlap", overlap)
+        tip = torch.empty((B, T, 3), dtype=dt, device=DEV)
+        status = torch.full((B, T), -1, dtype=torch.int32, device=DEV)
+        G = torch.zeros((B, 6), dtype=dt, device=DEV)
+        ran = []
+        if mode == "chunks":
+            h.set_option("keep_predictor", 1)
+            st = h.new_state(B, dt, n_slots=T + 1)
+            h.init_straight(st[0])
+            for c in range(3):
+                a, b = 8 * c, 8 * c + 8
+                tp = torch.empty((B, 8, 3), dtype=dt, device=DEV)
+                ss = torch.full((B, 8), -1, dtype=torch.int32, device=DEV)
+                h.simulate(ctl[:, a:b].contiguous(), st[a:b + 1], G, tip=tp, status=ss, prev_init=st[a - 1] if a else None)
+                ran.append(h.get_option("last_overlap"))
+                tip[:, a:b] = tp
+                status[:, a:b] = ss
+            h.set_option("keep_predictor", 0)
+            last = st[T]
+        else:
+            st = h.new_state(B, dt, n_slots=3 if mode == "ring" else T + 1)
+            h.init_straight(st[0])
+            h.simulate(ctl, st, G, ring=mode == "ring", tip=tip, status=status)
+            ran.append(h.get_option("last_overlap"))
+            last = st[T % 3 if mode == "ring" else T]
+        _assert_persistent(h, W)
+        return tip, status, last.clone(), ran
+
+    try:
+        for mode in ("full", "ring", "chunks"):
+            t0, s0, l0, ran0 = run(0, mode)
+            t1, s1, l1, ran1 = run(1, mode)
+            assert all(x == 0 for x in ran0) and all(x == 1 for x in ran1), (mode, ran0, ran1)
+            assert int((s0 != 0).sum()) == 0 and torch.equal(s0, s1), mode
+            scale = float(t0.abs().max())
+            assert float((t0 - t1).abs().max()) < 1e-7 * scale, mode   # (both stop at tol 1e-8)
+            assert float((l0[..., :25] - l1[..., :25]).abs().max()) < 1e-6 * float(l0[..., :25].abs().max()), mode
+            assert float(l1[..., 25:].abs().max()) == 0.0
+        if kind == "sine":
+            import cosserat_oracle_c as oc
+            t1 = run(1, "full")[0].cpu().numpy()
+            for b in (0, B - 1):
+                tip_c, _, bad = oc.simulate(orc.params_for(None, N), ctl_np[b])
+                assert bad == 0 and rel_l2(t1[b], tip_c) < 1e-8
+    finally:
+        h.set_option("msw_overlap", 1)
