@@ -22,6 +22,9 @@
 // LDS next to the condensation tiles (short rods in small batches: BASELINE cfg2).
 #pragma once
 #include "kr_mso_impl.hpp"
+// KR_MSWO_LOOP: compile-time probes of the merged sweep's loop structure (cfg2, us per step): 0 = peeled (first trip, paired
+// unpredicated trips, last trips) 21.7 - 22.0; 1 = one loop over the predicated trip 22.3; 2 = one loop, grid point clamped by
+// min / max, one unsigned compare as predicate 21.8 - 21.9 (level with 0)
 #ifndef KR_MSWO_LOOP
 #define KR_MSWO_LOOP 0
 #endif
@@ -309,8 +312,15 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
       auto trip = [&](int k, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int kk = k - lag;
+#if KR_MSWO_LOOP == 2
+        // (a probe: one trip body for all trips - the grid point clamped into the lane's interval by one v_med3_i32, the
+        //  predicate one unsigned compare - so that the compiler can pair ALL trips)
+        const bool live = act && (unsigned)kk < (unsigned)len_l;
+        const int j = max(s_l, min(s_l + kk, s_l + len_l - 1));
+#else
         const bool live = FULL ? act : (act && kk >= 0 && kk < len_l);
         const int j = FULL ? s_l + kk : point_of(k);
+#endif
         RodState<T> k1;
         V3<T> v, u;
         ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fc, k1, v, u);
@@ -326,11 +336,15 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
           if (!lean) store_record(out_rod + (size_t)j * KR_SLOTS, rec);
           lds_store_vec<T, 12>(tnew + (size_t)j * 12, lead);
         }
+#if KR_MSWO_LOOP == 2
+        hist_at(max(s_l, min(s_l + kk + 1, s_l + len_l - 1)), hv);
+#else
         hist_at(FULL ? j + 1 : point_of(k + 1), hv);
+#endif
         const T dsl = live ? Pc.ds : T(0);  // (a lane outside its range evaluates finite data and adds nothing)
         y = state_axpy(y, dsl, k1);
       };
-#if KR_MSWO_LOOP == 1
+#if KR_MSWO_LOOP == 1 || KR_MSWO_LOOP == 2
       // (a probe: one general loop, trips paired by the compiler)
 #pragma unroll 2
       for (int k = 0; k < trips; ++k) trip(k, std::false_type{});
