@@ -31,10 +31,14 @@
 
 namespace kr {
 
-template <typename T, int W>
+// GT ("global tiles"): rods whose three tiles of leading slots do not fit the LDS (N = 400 at two rods per CU) read the leading
+// slots straight from the states in HBM / L2 - a state's record holds them in its first twelve slots, and on a 3-slot ring the
+// three slots ARE the three tiles.  The reads of the next trip then go out at the head of a trip (the verifying lanes run TWO
+// grid points ahead), under a grid point's worth of arithmetic.
+template <typename T, int W, bool GT = false>
 __host__ __device__ inline size_t mswo_lds_elems(int N) {
   constexpr int P = MswGeo<W>::P;
-  return msw_lds_elems<T, W>(N) + 3 * (((size_t)N * 12 + 3) & ~size_t(3)) + ((P * 19 + 3) & ~3);
+  return msw_lds_elems<T, W>(N) + (GT ? 0 : 3 * (((size_t)N * 12 + 3) & ~size_t(3))) + ((P * 19 + 3) & ~3);
 }
 
 // Scaled maximum norm of this wavefront's part of the residual of a VERIFYING sweep: interface jumps E_g - Y_{g+1} of its
@@ -62,9 +66,11 @@ __device__ __forceinline__ float mswo_residual_B(const T* Es, const T* XsB, cons
   return rn;
 }
 
-template <typename T, int W>
+template <typename T, int W, bool GT = false>
 __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc, const SimArgs<T> A) {
   constexpr bool DIAG = true;
+  constexpr int LAGV = GT ? 2 : MSO_LAG;   // grid points the verifying lanes run ahead
+  constexpr int LS = GT ? KR_SLOTS : 12;   // stride of the leading slots of consecutive grid points
   constexpr int P = MswGeo<W>::P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = Pc.N;
@@ -80,9 +86,16 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
   // a step can be rolled back without the states in HBM - and on a 3-slot ring the interior records of interior steps are
   // not stored at all (nobody reads them: the caller gets the tips and the last three states)
   const size_t lsz = ((size_t)N * 12 + 3) & ~size_t(3);
-  T* const lead3 = smem + msw_lds_elems<T, W>(N);                   // [3][N][12]
-  T* const XsB = lead3 + 3 * lsz;                                   // [P][19] unknowns of the step under verification
-  auto tile = [&](int64_t st_) -> T* { return lead3 + (size_t)((st_ + 3) % 3) * lsz; };
+  T* const lead3 = smem + msw_lds_elems<T, W>(N);                   // [3][N][12] (not with GT)
+  T* const XsB = lead3 + (GT ? 0 : 3 * lsz);                        // [P][19] unknowns of the step under verification
+  auto tile = [&](int64_t st_) -> T* {
+    if constexpr (GT) {  // the state itself (its leading slots come first in every record)
+      return st_ >= 0 ? A.states + (A.ring ? st_ % 3 : st_) * A.slot_elems + rod * rod_elems
+                      : (A.prev_init ? const_cast<T*>(A.prev_init) + rod * rod_elems : A.states + rod * rod_elems);
+    } else {
+      return lead3 + (size_t)((st_ + 3) % 3) * lsz;
+    }
+  };
   T* const Xs = L.Xs;
   T* const Es = L.es(wave);
   float* const redf = reinterpret_cast<float*>(L.red);
@@ -110,6 +123,7 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
   // after the barrier in front; with_prev: and those of the state before it - the start of a call)
   auto tile_from_hbm = [&](int64_t t, bool with_prev) {
     __syncthreads();
+    if constexpr (GT) return;  // (the states are the tiles)
     const T* cur = state_ptr(t);
     const T* prv = t > 0 ? state_ptr(t - 1) : (A.prev_init ? A.prev_init + rod * rod_elems : cur);
     for (int j = threadIdx.x; j < N; j += WAVE * W) {
@@ -131,8 +145,8 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
     const T* prv = tile(t - 1);
     for (int j = threadIdx.x; j < N; j += WAVE * W) {
       T cv[12], pv[12], hv[12];
-      load_hist_vec<T, 12>(cur + (size_t)j * 12, cv);
-      load_hist_vec<T, 12>(prv + (size_t)j * 12, pv);
+      load_hist_vec<T, 12>(cur + (size_t)j * LS, cv);
+      load_hist_vec<T, 12>(prv + (size_t)j * LS, pv);
 #pragma unroll
       for (int k = 0; k < 12; ++k) hv[k] = A.hc1 * cv[k] + A.hc2 * pv[k];
       store_vec<T, 12>(L.hist + (size_t)j * HS_LEAN, hv);
@@ -268,9 +282,9 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
     RodState<T> y = rows_to_state(yr);
     const V3<T> fc = isB ? fcB : fcA;
     // the verifying lanes run MSO_LAG grid points ahead of the forward-difference lanes that consume their records
-    const int lag = (isA && merged) ? MSO_LAG : 0;
+    const int lag = (isA && merged) ? LAGV : 0;
     const bool act = isB ? merged : (isA && runA);
-    const int trips = lmax + ((merged && runA) ? MSO_LAG : 0);
+    const int trips = lmax + ((merged && runA) ? LAGV : 0);
     T* const out_rod = state_ptr(tB + 1);  // (used by the verifying lanes only)
     auto point_of = [&](int k) -> int {
       const int kk = k - lag;
@@ -282,10 +296,14 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
     // and write the tile of state tB + 1 = tA - with three tiles nothing anybody still reads.
     const T* const lead_n = tile(isB ? tB : tA);
     const T* const lead_o = tile(isB ? tB - 1 : tB);
+    auto lead_load = [&](const T* p, int j, T (&v)[12]) __attribute__((always_inline)) {
+      if constexpr (GT) load_hist_vec<T, 12>(p + (size_t)j * LS, v);
+      else lds_load_vec<T, 12>(p + (size_t)j * 12, v);
+    };
     auto hist_at = [&](int j, T (&hv)[HS_LEAN]) __attribute__((always_inline)) {
       T la[12], lb[12];
-      lds_load_vec<T, 12>(lead_n + (size_t)j * 12, la);
-      lds_load_vec<T, 12>(lead_o + (size_t)j * 12, lb);
+      lead_load(lead_n, j, la);
+      lead_load(lead_o, j, lb);
 #pragma unroll
       for (int c = 0; c < 12; ++c) hv[c] = A.hc1 * la[c] + A.hc2 * lb[c];
     };
@@ -309,6 +327,11 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
       // MSO_LAG .. sbase - 1
       const bool lean = A.ring && tB + 4 <= T_steps;  // (the last three states of a call stay complete)
       T* const tnew = tile(tB + 1);        // leading slots of the state this sweep produces (over those of state tB - 2)
+      T la[12], lb[12];                    // GT: leading slots in flight for the trip after the one being worked on
+      if constexpr (GT) {
+        lead_load(lead_n, point_of(1), la);
+        lead_load(lead_o, point_of(1), lb);
+      }
       auto trip = [&](int k, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int kk = k - lag;
@@ -324,6 +347,15 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
         RodState<T> k1;
         V3<T> v, u;
         ode_eval<T, DIAG>(Pc, y, hist_lean<T, DIAG>(Pc, hv), fc, k1, v, u);
+        if constexpr (GT) {
+          // formed in front of the verifying lanes' block (behind it the wait for the loads would also wait for the block's
+          // stores) and pinned there; not earlier either (the scheduler would pull the wait into the arithmetic above)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 12; ++c) hv[c] = A.hc1 * la[c] + A.hc2 * lb[c];
+          asm volatile("" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]));
+          asm volatile("" : "+v"(hv[6]), "+v"(hv[7]), "+v"(hv[8]), "+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]));
+        }
         if (isB && live) {
           // the accepted-to-be state of step tB at grid point j: its leading slots into the tile (interior records of
           // interior steps on a ring go nowhere else: three tiles roll a step back without the states in HBM)
@@ -332,15 +364,28 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
           T lead[12];
 #pragma unroll
           for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-          // (no take-over kernel reads interval-start records here: lean steps store nothing at all in a trip)
-          if (!lean) store_record(out_rod + (size_t)j * KR_SLOTS, rec);
-          lds_store_vec<T, 12>(tnew + (size_t)j * 12, lead);
+          if constexpr (GT) {  // the record in HBM is the tile: its leading slots always, the rest where it must be complete
+            if (lean) store_vec<T, 12>(out_rod + (size_t)j * KR_SLOTS, lead);
+            else store_record(out_rod + (size_t)j * KR_SLOTS, rec);
+          } else {
+            // (no take-over kernel reads interval-start records here: lean steps store nothing at all in a trip)
+            if (!lean) store_record(out_rod + (size_t)j * KR_SLOTS, rec);
+            lds_store_vec<T, 12>(tnew + (size_t)j * 12, lead);
+          }
         }
+        if constexpr (GT) {
+          // leading slots for the trip AFTER NEXT (the verifying lanes run two grid points ahead: a forward-difference lane's
+          // were stored just above), from L2 under a whole trip of arithmetic; the next trip's record was formed above
+          const int jn2 = FULL ? j + 2 : point_of(k + 2);
+          lead_load(lead_n, jn2 < N ? jn2 : N - 1, la);
+          lead_load(lead_o, jn2 < N ? jn2 : N - 1, lb);
+        } else {
 #if KR_MSWO_LOOP == 2
-        hist_at(max(s_l, min(s_l + kk + 1, s_l + len_l - 1)), hv);
+          hist_at(max(s_l, min(s_l + kk + 1, s_l + len_l - 1)), hv);
 #else
-        hist_at(FULL ? j + 1 : point_of(k + 1), hv);
+          hist_at(FULL ? j + 1 : point_of(k + 1), hv);
 #endif
+        }
         const T dsl = live ? Pc.ds : T(0);  // (a lane outside its range evaluates finite data and adds nothing)
         y = state_axpy(y, dsl, k1);
       };
@@ -350,7 +395,7 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
       for (int k = 0; k < trips; ++k) trip(k, std::false_type{});
 #else
       int k = 0;
-      for (; k < MSO_LAG && k < trips; ++k) trip(k, std::false_type{});
+      for (; k < LAGV && k < trips; ++k) trip(k, std::false_type{});
 #pragma unroll 2
       for (; k < R.sbase; ++k) trip(k, std::true_type{});
       for (; k < trips; ++k) trip(k, std::false_type{});
@@ -374,11 +419,13 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
         if (gB == P - 1) {  // the last grid point: y from the sweep, z untouched
           T rec[KR_SLOTS];
           record_from(y, S.vlast, S.ulast, rec);
-          if (!(A.ring && tB + 4 <= T_steps)) store_record(out_rod + (size_t)(N - 1) * KR_SLOTS, rec);  // (`lean` of the sweep)
           T lead[12];
 #pragma unroll
           for (int c = 0; c < 12; ++c) lead[c] = rec[c];
-          lds_store_vec<T, 12>(tile(tB + 1) + (size_t)(N - 1) * 12, lead);
+          const bool lean_v = A.ring && tB + 4 <= T_steps;  // (`lean` of the sweep)
+          if (!lean_v) store_record(out_rod + (size_t)(N - 1) * KR_SLOTS, rec);
+          else if constexpr (GT) store_vec<T, 12>(out_rod + (size_t)(N - 1) * KR_SLOTS, lead);
+          if constexpr (!GT) lds_store_vec<T, 12>(tile(tB + 1) + (size_t)(N - 1) * 12, lead);
           if (A.tip) {
             T* tp = A.tip + (rod * T_steps + tB) * 3;
             tp[0] = y.p.x; tp[1] = y.p.y; tp[2] = y.p.z;
@@ -566,26 +613,29 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
 }
 
 // kr_simulate_batch with several wavefronts per rod and overlapped steps: 0 launched, 1 does not apply
+template <typename T, int W, bool GT>
+static int launch_mswo_inst(const RodConst<T>& P, const SimArgs<T>& a, size_t bytes, hipStream_t s) {
+  auto kern = mswo_sim_kernel<T, W, GT>;
+  if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), bytes)) return rc_lds_;
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * W), bytes, s, P, a);
+  KR_HIP(hipGetLastError());
+  return KR_OK;
+}
 template <typename T>
 int launch_mswo_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s) {
   const RodConst<T>& P = consts<T>(h);
   if (!P.diag || (W != 2 && W != 4)) return 1;
   if (P.N - 1 < 2 * (4 + 3 * (W - 1))) return 1;
-  const size_t bytes = sizeof(T) * (W == 2 ? mswo_lds_elems<T, 2>(P.N) : mswo_lds_elems<T, 4>(P.N));
   // (every rod resident at once: a second round of workgroups would wait for the first to finish all steps)
-  if (bytes > (size_t)h->lds_limit || a.B > 256 * (int64_t)((size_t)h->lds_limit / bytes)) return 1;
+  auto fits = [&](size_t bytes) { return bytes <= (size_t)h->lds_limit && a.B <= 256 * (int64_t)((size_t)h->lds_limit / bytes); };
+  const size_t b_lds = sizeof(T) * (W == 2 ? mswo_lds_elems<T, 2, false>(P.N) : mswo_lds_elems<T, 4, false>(P.N));
+  const size_t b_gt = sizeof(T) * (W == 2 ? mswo_lds_elems<T, 2, true>(P.N) : mswo_lds_elems<T, 4, true>(P.N));
+  static const int force_gt = std::getenv("KR_MSWO_GT") ? std::atoi(std::getenv("KR_MSWO_GT")) : -1;  // (tests: 1 = tiles in HBM, 0 = never)
+  const bool use_gt = force_gt == 1 || (force_gt != 0 && !fits(b_lds));
+  if (use_gt ? !fits(b_gt) : !fits(b_lds)) return 1;
   h->last_waves_per_rod = W;
-  if (W == 2) {
-    auto kern = mswo_sim_kernel<T, 2>;
-    if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), bytes)) return rc_lds_;
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * 2), bytes, s, P, a);
-  } else {
-    auto kern = mswo_sim_kernel<T, 4>;
-    if (int rc_lds_ = dyn_lds(reinterpret_cast<const void*>(kern), bytes)) return rc_lds_;
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(WAVE * 4), bytes, s, P, a);
-  }
-  KR_HIP(hipGetLastError());
-  return KR_OK;
+  if (use_gt) return W == 2 ? launch_mswo_inst<T, 2, true>(P, a, b_gt, s) : launch_mswo_inst<T, 4, true>(P, a, b_gt, s);
+  return W == 2 ? launch_mswo_inst<T, 2, false>(P, a, b_lds, s) : launch_mswo_inst<T, 4, false>(P, a, b_lds, s);
 }
 
 }  // namespace kr

@@ -54,7 +54,7 @@ def run(h, ctl, B, T, ring, chunks, overlap, maxit):
 
 bad = 0
 for case in range(cases):
-    N = int(rng.choice([33, 40, 57, 64, 90, 100, 101, 128])); W = int(rng.choice([2, 4])); B = int(rng.choice([1, 3, 16, 64]))
+    N = int(rng.choice([33, 40, 57, 64, 90, 100, 101, 128, 200, 400])); W = int(rng.choice([2, 4])); B = int(rng.choice([1, 3, 16, 64]))
     T = int(rng.choice([1, 2, 5, 24, 60])); kind = str(rng.choice(["random", "jumps", "sine"])); ring = bool(rng.integers(0, 2))
     chunks = int(rng.choice([1, 1, 3])) if T >= 6 else 1; maxit = int(rng.choice([0, 0, 0, 2, 3])); mod = mods[int(rng.integers(0, len(mods)))]
     if chunks > 1: ring = False
