@@ -164,8 +164,9 @@ int kr_destroy(kr_handle* h);
  *                    corrections evaluates the network's base chain in fp32 (the accepted state never comes from it).
  *   "overlap"        1 (default) / 0: persistent form only - verify step t on spare lanes of the Jacobian sweep of
  *                    step t + 1 (kr_mso_impl.hpp; Euler sweeps, MLP off, diagonal material matrices)
- *   "msw_overlap"    1 (default) / 0: the same overlap where a rod owns 2 or 4 wavefronts (kr_mswo_impl.hpp; fp64, rods
- *                    whose three tiles of leading slots fit the LDS beside the condensation tiles, else the plain form)
+ *   "msw_overlap"    1 (default) / 0: the same overlap where a rod owns 2 or 4 wavefronts (kr_mswo_impl.hpp; Euler
+ *                    sweeps, MLP off, diagonal material matrices; the three tiles of leading slots in the LDS where
+ *                    they fit beside the condensation tiles, else read from the states themselves: long rods)
  *   "predictor"      0..8: how kr_simulate_batch may form the initial guess of each step (default 8;
  *                    0 = the reference's warm start).  1..7: highest order of polynomial time
  *                    extrapolation; the persistent kernel picks, rod by rod and step by step, the

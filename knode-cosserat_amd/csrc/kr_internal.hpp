@@ -100,7 +100,7 @@ struct kr_handle {
   int residual_test = 1;     // accept a storing sweep from its residual alone when the estimate is 256 x below the tolerance
   int overlap = 1;           // ... and overlap the verifying sweep of step t with the Jacobian sweep of step t + 1 (kr_mso_impl.hpp)
   int last_overlap = 0;      // the last kr_simulate_batch ran the overlapped kernel
-  int msw_overlap = 1;       // several wavefronts per rod: the persistent kernel with overlapped steps (kr_mswo_impl.hpp; fp64)
+  int msw_overlap = 1;       // several wavefronts per rod: the persistent kernel with overlapped steps (kr_mswo_impl.hpp)
   int nn_lowp_first = 1;     // fp64, MLP on, persistent one-wavefront kernel: first sweep of a three-sweep step on the fp32 base chain
   int nn_base_only_store = 1;  // fp64, MLP on, persistent one-wavefront kernel: storing sweeps without forward-difference columns
   void* resume_buf = nullptr;  // int32 per rod (SimArgs::resume)
@@ -228,7 +228,7 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
 template <typename T>
 int launch_mso_sim(kr_handle* h, const SimArgs<T>& a, hipStream_t s);
 int ensure_resume(kr_handle* h, int64_t B);
-// kr_mswo_f64.hip: the same overlap on W = 2 / 4 wavefronts per rod (short rods in small batches); 1: does not apply
+// kr_mswo_f32.hip / kr_mswo_f64.hip: the same overlap on W = 2 / 4 wavefronts per rod; 1: does not apply
 template <typename T>
 int launch_mswo_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s);
 template <typename T>

@@ -1864,12 +1864,10 @@ int launch_sim_persistent(kr_handle* h, int scheme, int use_nn, const SimArgs<T>
   if (h->ms_mode == 0 || h->persistent == 0) return 1;
   h->last_overlap = 0;
   if (const int W = step_waves_per_rod<T>(h, scheme, use_nn, a.B, 0)) {  // several wavefronts per rod
-    if constexpr (sizeof(T) == 8) {
-      if (h->msw_overlap && P.diag) {
-        const int rc = launch_mswo_sim<T>(h, W, a, s);
-        if (rc == KR_OK) h->last_overlap = 1;
-        if (rc != 1) return rc;
-      }
+    if (h->msw_overlap && P.diag) {
+      const int rc = launch_mswo_sim<T>(h, W, a, s);
+      if (rc == KR_OK) h->last_overlap = 1;
+      if (rc != 1) return rc;
     }
     return launch_msw_sim<T>(h, W, a, s);
   }

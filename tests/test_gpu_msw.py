@@ -426,19 +426,22 @@ def test_auto_choice(torch_cuda, monkeypatch):
     assert h.get_option("last_sim_path") == 2 and h.get_option("last_waves_per_rod") == 1
 
 
-@pytest.mark.parametrize("N,kind", [(100, "sine"), (64, "random"), (40, "jumps")])
-def test_overlapped_steps_on_several_wavefronts(torch_cuda, waves_persistent, N, kind):
+@pytest.mark.parametrize("N,kind,dtype", [(100, "sine", "f64"), (64, "random", "f64"), (40, "jumps", "f64"), (400, "sine", "f64"),
+                                          (200, "random", "f64"), (100, "sine", "f32"), (400, "jumps", "f32")])
+def test_overlapped_steps_on_several_wavefronts(torch_cuda, waves_persistent, N, kind, dtype):
     """kr_mswo_impl.hpp (option "msw_overlap", default on, fp64): the verifying sweep of step t on spare lanes of the
     Jacobian sweep of step t + 1, on 2 or 4 wavefronts per rod.  Same tips, states and status as the plain persistent
     form on smooth and on rough inputs (fresh random tensions every step: rejected verdicts, chord checks, roll-backs),
-    as a trajectory, in a 3-slot ring and advanced by three calls; and the oracle's tips on the smooth case.
-    Reference: knode.py:55-102 (what both kernels replace)."""
+    as a trajectory, in a 3-slot ring and advanced by three calls; and the oracle's tips on the smooth case.  Rods whose
+    tiles of leading slots do not fit the LDS (N = 200, 400) read them from the states in HBM (the GT instantiations); fp32
+    within its 1e-5 contract.  Reference: knode.py:55-102 (what both kernels replace)."""
     torch = torch_cuda
     import cosserat_oracle as orc
     W = waves_persistent
     r = make_robot(None, N)
     h = r._native()
-    dt = torch.float64
+    dt = torch.float64 if dtype == "f64" else torch.float32
+    f32 = dtype == "f32"
     B, T = 12, 24
     rng = np.random.default_rng(N)
     if kind == "sine":
@@ -449,7 +452,7 @@ def test_overlapped_steps_on_several_wavefronts(torch_cuda, waves_persistent, N,
         ctl_np = np.full((B, T, 4), 5.0)
         for b in range(B):
             ctl_np[b, rng.integers(1, T):, rng.integers(0, 4)] += rng.uniform(-2, 2)
-    ctl = torch.as_tensor(ctl_np, device=DEV).contiguous()
+    ctl = torch.as_tensor(ctl_np, device=DEV).to(dt).contiguous()
 
     def run(overlap, mode):
         h.set_option("msw_overlap", overlap)
@@ -487,14 +490,14 @@ def test_overlapped_steps_on_several_wavefronts(torch_cuda, waves_persistent, N,
             assert all(x == 0 for x in ran0) and all(x == 1 for x in ran1), (mode, ran0, ran1)
             assert int((s0 != 0).sum()) == 0 and torch.equal(s0, s1), mode
             scale = float(t0.abs().max())
-            assert float((t0 - t1).abs().max()) < 1e-7 * scale, mode   # (both stop at tol 1e-8)
-            assert float((l0[..., :25] - l1[..., :25]).abs().max()) < 1e-6 * float(l0[..., :25].abs().max()), mode
+            assert float((t0 - t1).abs().max()) < (1e-5 if f32 else 1e-7) * scale, mode   # (both stop at tol 1e-8 / 1e-5)
+            assert float((l0[..., :25] - l1[..., :25]).abs().max()) < (1e-3 if f32 else 1e-6) * float(l0[..., :25].abs().max()), mode
             assert float(l1[..., 25:].abs().max()) == 0.0
         if kind == "sine":
             import cosserat_oracle_c as oc
             t1 = run(1, "full")[0].cpu().numpy()
             for b in (0, B - 1):
                 tip_c, _, bad = oc.simulate(orc.params_for(None, N), ctl_np[b])
-                assert bad == 0 and rel_l2(t1[b], tip_c) < 1e-8
+                assert bad == 0 and rel_l2(t1[b].astype(np.float64), tip_c) < (1e-5 if f32 else 1e-8)
     finally:
         h.set_option("msw_overlap", 1)

@@ -26,9 +26,8 @@ def controls(kind, B, T):
     t = np.arange(T)[None, :, None] * 0.05
     return 5.0 + 3.0 * np.sin(2 * np.pi * rng.uniform(0.2, 2.0, size=(B, 1, 4)) * t + rng.uniform(0, 6, size=(B, 1, 4)))
 
-def run(h, ctl, B, T, ring, chunks, overlap, maxit):
+def run(h, ctl, B, T, ring, chunks, overlap, maxit, dt=torch.float64):
     h.set_option("msw_overlap", overlap); h.set_option("keep_predictor", 1 if chunks > 1 else 0)
-    dt = torch.float64
     c = torch.as_tensor(ctl, device=dev).to(dt).contiguous()
     tip = torch.empty((B, T, 3), dtype=dt, device=dev); status = torch.zeros((B, T), dtype=torch.int32, device=dev)
     G = torch.zeros((B, 6), dtype=dt, device=dev)
@@ -61,15 +60,17 @@ for case in range(cases):
     r = CosseratRod(use_fsolve=True); setup_robot(r, mod); r.N = N; r.compute_intermediate_terms(); h = r._native()
     h.set_option("waves_per_rod", W)
     ctl = controls(kind, B, T)
-    a = run(h, ctl, B, T, ring, chunks, 0, maxit); b = run(h, ctl, B, T, ring, chunks, 1, maxit)
+    dt = torch.float32 if rng.integers(0, 3) == 0 else torch.float64
+    a = run(h, ctl, B, T, ring, chunks, 0, maxit, dt); b = run(h, ctl, B, T, ring, chunks, 1, maxit, dt)
     ok_rows = (a[1] == 0).all(axis=1) & (b[1] == 0).all(axis=1)   # rods that converged on every step in both runs
     scale = np.abs(a[0]).max() + 1e-30
     terr = np.abs(a[0][ok_rows] - b[0][ok_rows]).max() / scale if ok_rows.any() else 0.0
     serr = np.abs(a[2][ok_rows][..., :25] - b[2][ok_rows][..., :25]).max() / (np.abs(a[2][..., :25]).max() + 1e-30) if ok_rows.any() else 0.0
     same_status = (a[1] == b[1]).all()
-    ok = terr < 5e-7 and serr < 5e-6 and same_status and np.isfinite(b[0][ok_rows]).all()
+    f32 = dt == torch.float32
+    ok = terr < (2e-4 if f32 else 5e-7) and serr < (2e-3 if f32 else 5e-6) and same_status and np.isfinite(b[0][ok_rows]).all()
     bad += 0 if ok else 1
-    print(f"{'ok ' if ok else 'BAD'} case {case}: mod={mod} N={N} W={W}->{b[4]} B={B} T={T} {kind} ring={int(ring)} chunks={chunks} maxit={maxit} overlap_ran={b[3]} "
+    print(f"{'ok ' if ok else 'BAD'} case {case}: {'f32' if f32 else 'f64'} mod={mod} N={N} W={W}->{b[4]} B={B} T={T} {kind} ring={int(ring)} chunks={chunks} maxit={maxit} overlap_ran={b[3]} "
           f"rods converged in both {int(ok_rows.sum())}/{B} unconverged steps {int((a[1] != 0).sum())}/{int((b[1] != 0).sum())} same status {bool(same_status)} tip err {terr:.2e} state err {serr:.2e}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
