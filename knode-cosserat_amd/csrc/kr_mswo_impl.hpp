@@ -633,6 +633,13 @@ int launch_mswo_sim(kr_handle* h, int W, const SimArgs<T>& a, hipStream_t s) {
   static const int force_gt = std::getenv("KR_MSWO_GT") ? std::atoi(std::getenv("KR_MSWO_GT")) : -1;  // (tests: 1 = tiles in HBM, 0 = never)
   const bool use_gt = force_gt == 1 || (force_gt != 0 && !fits(b_lds));
   if (use_gt ? !fits(b_gt) : !fits(b_lds)) return 1;
+  if (use_gt && a.prev_init) {
+    // The GT form reads the state before states[0] while step 0 is being verified, i.e. while the slot of state 1 is written:
+    // a caller's prev_init inside that slot (knode_rod.h allows it to point into the ring) takes the plain form, which
+    // consumes it before its first store.
+    const T* s1 = a.states + a.slot_elems;
+    if (a.prev_init >= s1 && a.prev_init < s1 + a.slot_elems) return 1;
+  }
   h->last_waves_per_rod = W;
   if (use_gt) return W == 2 ? launch_mswo_inst<T, 2, true>(P, a, b_gt, s) : launch_mswo_inst<T, 4, true>(P, a, b_gt, s);
   return W == 2 ? launch_mswo_inst<T, 2, false>(P, a, b_lds, s) : launch_mswo_inst<T, 4, false>(P, a, b_lds, s);
