@@ -210,6 +210,7 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
   int itB = 0, orderB = 0;
   bool pred_skip = false;    // the predictor has already consumed step tA (a verifying sweep of it was rejected)
   bool stored_at_xs = false; // the state of step tA in HBM was streamed from the unknowns now in Xs (a rejected verifying sweep)
+  bool reverify = false;     // the coming merged sweep verifies step tA - 1 for the second time (after a chord update)
   V3<T> fcA = load_fc(0), fcB = fcA;
   V3<T> fcN = load_fc(T_steps > 1 ? 1 : 0);
 
@@ -438,6 +439,10 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
       // residual test (kr_ms_impl.hpp: audited factor 256 on the measured update / residual ratio)
       bool accepted = A.residual_test != 0 && ampB > 0.f && T(256) * (T)est <= tol;
       float dnv = est;
+      MswLds<T, W> LB = L;   // the solver's view with the unknowns of step tB in place of step tA's
+      LB.Xs = XsB;
+      MswUpd<T> U2;
+      bool have_chord = false;
       if (!accepted && itB > 0) {
         // chord update through the factors of step tB's last condensation (its forward-difference columns are still in Es:
         // the condensation of step tA comes after this verdict): a second solve with the verifying lanes' end states as
@@ -449,9 +454,6 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
           for (int q = 0; q < 19; ++q) eb[q] = Es[(nact + R.ivl) * 19 + q];
           yB = rows_to_state(eb);
         }
-        MswLds<T, W> LB = L;
-        LB.Xs = XsB;
-        MswUpd<T> U2;
 #ifdef KR_MS_STAMPS
         unsigned long long tb_ = tq;
         msw_condense<T, W, true>(LB, R, lane, yB, T(1), U2, stamps, tb_);
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
         msw_condense<T, W, true>(LB, R, lane, yB, T(1), U2);
 #endif
         dnv = U2.dnf;
+        have_chord = true;
         accepted = dnv <= 3.0e38f && (T)dnv <= T(0.5) * tol;
       }
 #ifdef KR_MS_STAMPS
@@ -474,9 +477,26 @@ __global__ __launch_bounds__(WAVE * W) void mswo_sim_kernel(const RodConst<T> Pc
         if (wave == 0 && lane == 0 && A.status) A.status[rod * T_steps + tB] = KR_ST_CONVERGED;
         if (wave == 0 && lane < 6) Gguess = XsB[0 * 19 + 7 + lane];
         pred_skip = false;
+        reverify = false;
         merged = false;
         if (!runA) break;  // that was the last step
+      } else if (have_chord && dnv <= 3.0e38f && !reverify && itB + 2 <= maxit) {
+        // First rejection of this step, and the chord update is a proper Newton-type correction (its factors are one
+        // iteration old): take it and verify AGAIN in a merged sweep (kr_mso_impl.hpp does the same) - the verifying lanes
+        // re-integrate step tB from the corrected unknowns over the state they have just left, the forward-difference lanes
+        // repeat their sweep of step tA from the same start (their history was off by this correction).  A rejection then
+        // costs one merged sweep instead of a roll-back to plain sweeps plus the restart of step tA.
+        msw_apply<T, W>(LB, R, lane, U2);
+        reverify = true;
+        itB += 1;
+        dnB = (T)dnv;
+        msw_lds_barrier();
+#ifdef KR_MS_STAMPS
+        o_retry += 1;
+#endif
+        continue;
       } else {
+        reverify = false;
         // Not accepted from its residual: the state in HBM was streamed from XsB, so a forward-difference sweep at XsB
         // measures the Newton update that belongs to it.  Drop the work done for step tA, put the history of step tB
         // back and carry on there.
